@@ -1,0 +1,379 @@
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+TEST INFRASTRUCTURE ONLY (see harness.py).  Run in the build container:
+
+    MPLBACKEND=Agg /opt/conda/bin/python3.9 oracle/refgen/gen_golden.py [which ...]
+
+`which` in {params, kernels, vmc_tape, dmc_tape, reblock, stats}; default all.
+Every output is *data* (inputs + the reference's outputs); no reference code
+is stored.  numpy seeds are fixed so a re-run reproduces the files.
+"""
+import json
+import os
+import sys
+from itertools import islice
+from math import pi
+
+import harness  # noqa: F401  (must precede phd_qmclib imports)
+import numpy as np
+
+from phd_qmclib import mrbp_qmc
+from phd_qmclib.mrbp_qmc.model import DIST_REGULAR
+from phd_qmclib.stats import reblock as rb
+from phd_qmclib.qmc_exec.data import dmc as dmc_data
+from phd_qmclib.qmc_exec.data import vmc as vmc_data
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                   '..', '..', 'tests', 'golden')
+OUT = os.path.normpath(OUT)
+core = mrbp_qmc.model.core_funcs
+
+
+def box_spec(n, **over):
+    """The synthetic "mrbp_qmc box" of SURVEY.md 8(d): unit filling."""
+    kw = dict(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+              interaction_strength=2, boson_number=n, supercell_size=n,
+              tbf_contact_cutoff=0.25 * n)
+    kw.update(over)
+    return kw
+
+
+SPECS = {
+    'box16': box_spec(16),
+    'box64': box_spec(64),
+    'box128': box_spec(128),
+    'box512': box_spec(512),
+    'box8': box_spec(8),
+    # tests/mrbp_qmc/test_dmc.py:12-29 (Lieb-Liniger limit with defects off)
+    'free16': dict(lattice_depth=0, lattice_ratio=1, interaction_strength=4,
+                   boson_number=16, supercell_size=16, tbf_contact_cutoff=4,
+                   num_defects=4, defect_magnitude=0),
+    # tests/mrbp_qmc/test_model.py:9-14
+    'deep100': dict(lattice_depth=100, lattice_ratio=1, interaction_strength=1,
+                    boson_number=100, supercell_size=100,
+                    tbf_contact_cutoff=25),
+    # tests/mrbp_qmc/test_vmc.py:9-14
+    'deep16': dict(lattice_depth=100, lattice_ratio=1, interaction_strength=1,
+                   boson_number=16, supercell_size=16, tbf_contact_cutoff=4),
+    # ideal gas in the lattice (two-body factor switched off)
+    'ideal16': dict(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                    interaction_strength=0, boson_number=16, supercell_size=16,
+                    tbf_contact_cutoff=4),
+    # lattice defects that actually differ from the lattice depth
+    'defect24': dict(lattice_depth=5 * pi ** 2, lattice_ratio=0.5,
+                     interaction_strength=3, boson_number=20, supercell_size=24,
+                     tbf_contact_cutoff=5.5, num_defects=4,
+                     defect_magnitude=2 * pi ** 2),
+    # non-commensurate filling and ratio, contact cutoff at the box limit
+    'odd24': dict(lattice_depth=30.0, lattice_ratio=2.5,
+                  interaction_strength=0.7, boson_number=24,
+                  supercell_size=17.5, tbf_contact_cutoff=8.75),
+}
+
+
+def jsonable(nt):
+    d = nt._asdict()
+    for k, v in d.items():
+        if isinstance(v, (np.integer,)):
+            d[k] = int(v)
+        elif isinstance(v, (np.floating,)):
+            d[k] = float(v)
+        elif isinstance(v, (np.bool_,)):
+            d[k] = bool(v)
+    return d
+
+
+def gen_params():
+    out = {}
+    for tag, kw in SPECS.items():
+        spec = mrbp_qmc.Spec(**kw)
+        out[tag] = dict(spec=kw,
+                        num_defects=spec.num_defects,
+                        defect_magnitude=spec.defect_magnitude,
+                        params=jsonable(spec.params),
+                        obf_params=jsonable(spec.obf_params),
+                        tbf_params=jsonable(spec.tbf_params))
+    with open(os.path.join(OUT, 'params.json'), 'w') as fp:
+        json.dump(out, fp, indent=1, sort_keys=True)
+    print('params.json', len(out))
+
+
+def make_confs(spec, rng, num_random=4):
+    """Fixed configurations: random, regular, near-contact, wrap-edge,
+    cell-edge (positions on lattice-region boundaries)."""
+    n = spec.boson_number
+    L = spec.supercell_size
+    confs = []
+    for _ in range(num_random):
+        c = spec.get_sys_conf_buffer()
+        c[0] = L * rng.random_sample(n)
+        confs.append(c)
+    confs.append(spec.init_get_sys_conf(DIST_REGULAR))
+    confs.append(spec.init_get_sys_conf(DIST_REGULAR, offset=0.3137))
+    # near contact: pairs a few 1e-3..1e-9 apart, also across the boundary
+    c = spec.get_sys_conf_buffer()
+    c[0] = L * rng.random_sample(n)
+    c[0, 1] = c[0, 0] + 1e-3
+    c[0, 3] = (c[0, 2] - 1e-6) % L
+    c[0, 4] = 1e-9
+    c[0, 5] = L - 1e-9
+    confs.append(c % L)
+    # wrap edge: half the particles within 1e-2 of the box ends, exact 0,
+    # exactly L/2 apart, exact cell boundaries
+    c = spec.get_sys_conf_buffer()
+    c[0] = L * rng.random_sample(n)
+    c[0, 0] = 0.0
+    c[0, 1] = 0.5 * L
+    c[0, 2] = L - 1e-12
+    c[0, 3] = 1.0 / (1 + spec.lattice_ratio)      # exactly z_a of cell 0
+    c[0, 4] = 1.0
+    c[0, 5] = 0.25 * L                              # rm from particle 0
+    c[0, 6] = L - 0.25 * L
+    for k in range(7, min(n, 12)):
+        c[0, k] = (L - 1e-2 * rng.random_sample()) if k % 2 else \
+            1e-2 * rng.random_sample()
+    confs.append(c)
+    return np.array(confs)
+
+
+def gen_kernels():
+    rng = np.random.RandomState(20261004)
+    out = {}
+    for tag, kw in SPECS.items():
+        spec = mrbp_qmc.Spec(**kw)
+        n = spec.boson_number
+        cfc = spec.cfc_spec
+        confs = make_confs(spec, rng, num_random=2 if n >= 512 else 4)
+        nc = len(confs)
+        wf = np.zeros(nc)
+        en = np.zeros(nc)
+        ith_e = np.zeros((nc, n))
+        ith_f = np.zeros((nc, n))
+        ith_e_only = np.zeros((nc, n))
+        for k, c in enumerate(confs):
+            wf[k] = core.wf_abs_log(c, *cfc)
+            en[k] = core.energy(c, *cfc)
+            d = core.drift(c, *cfc)
+            for i in range(n):
+                e_i, f_i = core.ith_energy_and_drift(i, c, *cfc)
+                ith_e[k, i] = e_i
+                ith_f[k, i] = f_i
+                if n <= 128:
+                    ith_e_only[k, i] = core.ith_energy(i, c, *cfc)
+            assert np.array_equal(d[0], c[0])
+            assert np.allclose(d[1], ith_f[k], rtol=0, atol=0)
+            if n <= 128:
+                assert np.array_equal(ith_e_only[k], ith_e[k])
+        out[tag + '/pos'] = confs[:, 0, :].copy()
+        out[tag + '/wf_abs_log'] = wf
+        out[tag + '/energy'] = en
+        out[tag + '/ith_energy'] = ith_e
+        out[tag + '/ith_drift'] = ith_f
+        print('kernels', tag, nc, wf[:2], en[:2])
+    np.savez_compressed(os.path.join(OUT, 'kernels.npz'), **out)
+
+
+def gen_vmc_tape():
+    """RNG-tape VMC trajectories through `Sampling.blocks` (so the block
+    bookkeeping of qmc_base/vmc.py:686-768 is exercised, including the
+    energy carry on rejected moves across a block boundary)."""
+    out = {}
+    cases = [('box8', 0.125, 3, 96), ('box16', 0.125, 2, 128),
+             ('free16', 0.125, 2, 64), ('deep16', 0.125, 2, 64),
+             ('defect24', 0.3, 2, 48)]
+    for tag, spread, nblocks, ns in cases:
+        spec = mrbp_qmc.Spec(**SPECS[tag])
+        np.random.seed(4242)
+        ini = spec.init_get_sys_conf()
+        smp = mrbp_qmc.vmc.Sampling(spec, move_spread=spread, rng_seed=7)
+        st0 = smp.build_state(ini)
+        wf, en, ms, ar = [], [], [], []
+        with harness.RNGTape() as tape:
+            for blk in islice(smp.blocks(ns, st0), nblocks):
+                wf.append(blk.iter_props.wf_abs_log.copy())
+                en.append(blk.iter_props.energy.copy())
+                ms.append(blk.iter_props.move_stat.copy())
+                ar.append(blk.accept_rate)
+                last = blk.last_state
+        out[tag + '/ini_pos'] = ini[0].copy()
+        out[tag + '/ini_wf_abs_log'] = np.float64(st0.wf_abs_log)
+        out[tag + '/move_spread'] = np.float64(spread)
+        out[tag + '/uniform'] = np.array(tape.uniform)
+        out[tag + '/wf_abs_log'] = np.array(wf)
+        out[tag + '/energy'] = np.array(en)
+        out[tag + '/move_stat'] = np.array(ms)
+        out[tag + '/accept_rate'] = np.array(ar)
+        out[tag + '/last_pos'] = last.sys_conf[0].copy()
+        assert not tape.normal
+        print('vmc_tape', tag, len(tape.uniform), ar)
+    np.savez_compressed(os.path.join(OUT, 'vmc_tape.npz'), **out)
+
+
+def gen_dmc_tape():
+    """RNG-tape DMC trajectories through `Sampling.states`: per time step the
+    uniforms drawn by the branching loop and the normals drawn by the
+    diffusion, plus every yielded scalar and the cloning table."""
+    out = {}
+    # (tag, spec, dt, target, max, kappa, steps, n_ini)
+    cases = [('box8', 'box8', 1e-3, 24, 32, 0.5, 48, 24),
+             ('box16', 'box16', 6.25e-4, 12, 16, 0.125, 24, 10),
+             ('free16', 'free16', 1e-3, 12, 16, 0.5, 24, 16),
+             # target above the cap: the population grows into max_num_walkers
+             # and the branching loop truncates (qmc_base/dmc.py:638-651)
+             ('cap8', 'box8', 2e-3, 40, 22, 0.5, 40, 20)]
+    for tag, stag, dt, target, maxw, kappa, steps, n_ini in cases:
+        spec = mrbp_qmc.Spec(**SPECS[stag])
+        np.random.seed(1717)
+        ini_set = np.array([spec.init_get_sys_conf() for _ in range(n_ini)])
+        smp = mrbp_qmc.dmc.Sampling(spec, dt, max_num_walkers=maxw,
+                                    target_num_walkers=target,
+                                    num_walkers_control_factor=kappa,
+                                    rng_seed=11, jit_parallel=False)
+        st0 = smp.build_state(ini_set)
+        rec = dict(energy=[], weight=[], num_walkers=[], ref_energy=[],
+                   accum_energy=[], n_uniform=[], n_normal=[])
+        refs = np.full((steps, maxw), -1, dtype=np.int64)
+        conf_hist = np.zeros((steps, maxw, 2, spec.boson_number))
+        en_hist = np.zeros((steps, maxw))
+        with harness.RNGTape() as tape:
+            nu = nn = 0
+            for t, st in enumerate(islice(smp.states(st0), steps)):
+                rec['energy'].append(st.energy)
+                rec['weight'].append(st.weight)
+                rec['num_walkers'].append(st.num_walkers)
+                rec['ref_energy'].append(st.ref_energy)
+                rec['accum_energy'].append(st.accum_energy)
+                rec['n_uniform'].append(len(tape.uniform) - nu)
+                rec['n_normal'].append(len(tape.normal) - nn)
+                nu, nn = len(tape.uniform), len(tape.normal)
+                nw = st.num_walkers
+                refs[t, :nw] = st.branching_spec.cloning_ref[:nw]
+                conf_hist[t, :nw] = st.confs[:nw]
+                en_hist[t, :nw] = st.props.energy[:nw]
+                assert np.all(st.props.weight[:nw] == 1.0)
+                assert not st.props.mask[:nw].any()
+                assert st.props.mask[nw:].all()
+        out[tag + '/ini_pos'] = ini_set[:, 0, :].copy()
+        out[tag + '/ini_energy'] = st0.props.energy[:n_ini].copy()
+        out[tag + '/ini_drift'] = st0.confs[:n_ini, 1, :].copy()
+        out[tag + '/ini_ref_energy'] = np.float64(st0.ref_energy)
+        out[tag + '/cfg'] = np.array([dt, target, maxw, kappa, steps, n_ini])
+        out[tag + '/uniform'] = np.array(tape.uniform)
+        out[tag + '/normal'] = np.array(tape.normal)
+        for k, v in rec.items():
+            out[tag + '/' + k] = np.array(v)
+        out[tag + '/cloning_ref'] = refs
+        out[tag + '/confs'] = conf_hist
+        out[tag + '/walker_energy'] = en_hist
+        print('dmc_tape', tag, rec['num_walkers'][:8], max(rec['num_walkers']),
+              rec['energy'][-1] / rec['weight'][-1])
+    np.savez_compressed(os.path.join(OUT, 'dmc_tape.npz'), **out)
+
+
+def gen_reblock():
+    rng = np.random.RandomState(99)
+    out = {}
+    # AR(1) series: serially correlated like block totals of a Markov chain
+    for tag, n, phi in [('ar1024', 1024, 0.6), ('ar512', 512, 0.0),
+                        ('ar100', 100, 0.3), ('ar37', 37, 0.9)]:
+        x = np.zeros(n)
+        e = rng.normal(size=n)
+        for k in range(1, n):
+            x[k] = phi * x[k - 1] + e[k]
+        x += 5.0
+        w = 480.0 + 10 * rng.normal(size=n)
+        otf = rb.on_the_fly_obj_create(x)
+        obj = rb.OTFObject.from_non_obj_data(x)
+        out[tag + '/x'] = x
+        out[tag + '/w'] = w
+        out[tag + '/otf_block_size'] = otf['BLOCK_SIZE'].copy()
+        out[tag + '/otf_means_sum'] = otf['MEANS'].copy()
+        out[tag + '/otf_means_sqr_sum'] = otf['MEANS_SQR'].copy()
+        out[tag + '/otf_num_blocks'] = otf['NUM_BLOCKS'].copy()
+        out[tag + '/block_sizes'] = np.array(obj.block_sizes)
+        out[tag + '/num_blocks'] = np.array(obj.num_blocks)
+        out[tag + '/means'] = np.array(obj.means)
+        out[tag + '/vars'] = np.array(obj.vars)
+        out[tag + '/errors'] = np.array(obj.errors)
+        out[tag + '/iac_times'] = np.array(obj.iac_times)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            out[tag + '/opt_block_size'] = np.int64(obj.opt_block_size)
+            out[tag + '/opt_iac_time'] = np.float64(obj.opt_iac_time)
+            out[tag + '/eff_size'] = np.float64(obj.eff_size)
+            out[tag + '/mean_eff_error'] = np.float64(obj.mean_eff_error)
+            # qmc_exec/data/dmc.py:24-75 (ratio estimator) and vmc.py:23-42
+            pb = dmc_data.PropBlocks(x * w, w)
+            out[tag + '/dmc_mean'] = np.float64(pb.mean)
+            out[tag + '/dmc_mean_error'] = np.float64(pb.mean_error)
+            uw = dmc_data.UnWeightedPropBlocks(w)
+            out[tag + '/uw_mean'] = np.float64(uw.mean)
+            out[tag + '/uw_mean_error'] = np.float64(uw.mean_error)
+            vb = vmc_data.PropBlocks(x)
+            out[tag + '/vmc_mean'] = np.float64(vb.mean)
+            out[tag + '/vmc_mean_error'] = np.float64(vb.mean_error)
+        print('reblock', tag, out[tag + '/opt_block_size'],
+              out[tag + '/dmc_mean'], out[tag + '/dmc_mean_error'])
+    np.savez_compressed(os.path.join(OUT, 'reblock.npz'), **out)
+
+
+def gen_stats():
+    """Seeds x runs table of block statistics on the N=16 box, produced by the
+    reference with its own (numpy MT19937) streams: the 2-sigma gate."""
+    out = {}
+    spec = mrbp_qmc.Spec(**SPECS['box16'])
+    # VMC: per seed 16 blocks x 512 steps, first 2 burned
+    ns, nb, burn = 512, 16, 2
+    vm = []
+    for seed in (1, 2, 3, 4):
+        np.random.seed(1000 + seed)
+        ini = spec.init_get_sys_conf()
+        smp = mrbp_qmc.vmc.Sampling(spec, move_spread=0.125, rng_seed=seed)
+        st0 = smp.build_state(ini)
+        rows = []
+        for b, blk in enumerate(islice(smp.blocks(ns, st0), nb)):
+            if b < burn:
+                continue
+            e = blk.iter_props.energy
+            rows.append((e.mean(), (e ** 2).mean(), blk.accept_rate))
+        vm.append(rows)
+        print('stats vmc seed', seed, np.mean([r[0] for r in rows]) / 16,
+              np.mean([r[2] for r in rows]))
+    out['vmc/block_stats'] = np.array(vm)      # [seed, block, (E, E2, acc)]
+    out['vmc/cfg'] = np.array([ns, nb, burn, 0.125])
+    # DMC: per seed target 96 / max 128, 10 blocks x 32 steps, first 2 burned
+    dt, target, maxw, kappa, nts, nbd, burnd = 1e-3, 96, 128, 0.5, 32, 10, 2
+    dm = []
+    for seed in (1, 2, 3):
+        np.random.seed(2000 + seed)
+        ini = spec.init_get_sys_conf()
+        vs = mrbp_qmc.vmc.Sampling(spec, move_spread=0.125, rng_seed=seed)
+        chain = vs.as_chain(1024, vs.build_state(ini))
+        ini_set = chain.confs[-target:]
+        smp = mrbp_qmc.dmc.Sampling(spec, dt, max_num_walkers=maxw,
+                                    target_num_walkers=target,
+                                    num_walkers_control_factor=kappa,
+                                    rng_seed=seed, jit_parallel=False)
+        st0 = smp.build_state(ini_set)
+        rows = []
+        for b, blk in enumerate(islice(smp.blocks(st0, nts, burnd), nbd)):
+            p = blk.iter_props
+            rows.append((p.energy.sum(), p.weight.sum(),
+                         float(p.num_walkers.sum())))
+        dm.append(rows)
+        r = np.array(rows[burnd:])
+        print('stats dmc seed', seed, r[:, 0].sum() / r[:, 1].sum() / 16)
+    out['dmc/block_totals'] = np.array(dm)     # [seed, block, (E, W, nw)]
+    out['dmc/cfg'] = np.array([dt, target, maxw, kappa, nts, nbd, burnd])
+    np.savez_compressed(os.path.join(OUT, 'stats.npz'), **out)
+
+
+ALL = dict(params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
+           dmc_tape=gen_dmc_tape, reblock=gen_reblock, stats=gen_stats)
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        ALL[w]()

@@ -1,0 +1,5 @@
+"""Bloch-Phonon multi-rods model (reference: mrbp_qmc/__init__.py)."""
+from .model import (  # noqa: F401
+    CFCSpec, OBFParams, Params, Spec, TBFParams, core_funcs,
+    DIST_RAND, DIST_REGULAR, SysConfSlot
+)
