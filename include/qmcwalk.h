@@ -1,0 +1,196 @@
+/*
+ * qmcwalk.h -- C-ABI of libqmcwalk.so, the MI355X (gfx950) walker-propagation
+ * engine for the PhD-QMCLib `mrbp_qmc` VMC/DMC sampling hot path.
+ *
+ * The reference has no FFI: its boundary is the Python object protocol
+ * `Sampling.core_funcs` / `Sampling.blocks()` (numba-compiled callables,
+ * qmc_base/vmc.py:204-257, qmc_base/dmc.py:297-370).  Each entry point below
+ * names the reference interface it stands in for (paths under
+ * /root/reference/src/phd_qmclib/).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error;
+ *     `qmc_last_error()` gives the message (thread-local).
+ *   - "host" pointers are caller-owned CPU buffers; "dev" pointers are device
+ *     (HBM) addresses.  All device memory of an ensemble is owned by its handle.
+ *   - a handle is bound to one HIP device and one stream and is not
+ *     thread-safe.  `stream` is a hipStream_t passed as void* (NULL = the
+ *     engine creates its own non-blocking stream).
+ *   - configurations use the reference's row layout: positions pos[W][N],
+ *     full system configurations confs[W][2][N] (row 0 position, row 1 drift;
+ *     qmc_base/jastrow/model.py:31-38).
+ */
+#ifndef QMCWALK_H
+#define QMCWALK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMCWALK_ABI_VERSION 1
+
+typedef struct qmc_engine qmc_engine;
+typedef struct qmc_vmc qmc_vmc;
+typedef struct qmc_dmc qmc_dmc;
+
+/* mrbp_qmc/model.py:40-75 -- Params, OBFParams, TBFParams flattened in
+ * declaration order (what `Spec.cfc_spec` hands to every core function). */
+typedef struct {
+    double lattice_depth;
+    double lattice_ratio;
+    double interaction_strength;
+    int64_t boson_number;
+    double supercell_size;
+    double tbf_contact_cutoff;
+    double defect_magnitude;
+    int64_t defects_sep;
+    double well_width;
+    double barrier_width;
+    int64_t is_free;
+    int64_t is_ideal;
+    double param_e0;
+    double param_k1;
+    double param_kp1;
+    double param_k2;
+    double param_beta;
+    double param_r_off;
+    double param_am;
+} qmc_model_params;
+
+/* mrbp_qmc/vmc.py:29-38 (TPFParams) + Sampling fields :70-80; `gaussian`
+ * selects the vmc_ndf proposal (mrbp_qmc/vmc_ndf.py:23-51, move_spread =
+ * sigma = sqrt(time_step)). */
+typedef struct {
+    int64_t num_chains;
+    double move_spread;
+    uint64_t rng_seed;
+    uint32_t chain0;      /* Philox slot of chain 0 (rank offset)          */
+    int32_t gaussian;
+} qmc_vmc_params;
+
+/* mrbp_qmc/dmc.py:143-185 (Sampling fields + DDFParams) */
+typedef struct {
+    int64_t max_num_walkers;
+    int64_t target_num_walkers;
+    double time_step;
+    double num_walkers_control_factor;
+    uint64_t rng_seed;
+    uint32_t slot0;            /* Philox slot of walker slot 0 (rank offset) */
+    int32_t fix_stale_energy;  /* 0: reference behaviour         */
+    int32_t external_reduce;   /* 1: E_t/W_t are reduced across ranks by the
+                                  caller between step_local and step_finish  */
+    int32_t reserved;
+} qmc_dmc_params;
+
+const char *qmc_last_error(void);
+int qmc_abi_version(void);
+int qmc_device_count(int *count);
+
+/* ---- engine: model constants on one device --------------------------- */
+int qmc_engine_create(const qmc_model_params *model, int device, void *stream,
+                      qmc_engine **out);
+void qmc_engine_destroy(qmc_engine *eng);
+int qmc_engine_sync(qmc_engine *eng);
+/* HIP-event timing on the engine's stream (bench / roofline) */
+int qmc_engine_timer_start(qmc_engine *eng);
+int qmc_engine_timer_stop(qmc_engine *eng, float *elapsed_ms);
+
+/* Stands in for model.core_funcs.{wf_abs_log, energy, drift,
+ * ith_energy_and_drift} (qmc_base/jastrow/model.py:298-366, 476-564, 756-773,
+ * 793-854) over a batch of configurations.  Host buffers; any output may be
+ * NULL.  pos[nconf][N] -> wf[nconf], energy[nconf], ith_energy[nconf][N],
+ * drift[nconf][N]. */
+int qmc_evaluate(qmc_engine *eng, int64_t nconf, const double *pos,
+                 double *wf_abs_log, double *energy, double *ith_energy,
+                 double *drift);
+/* Same on device-resident buffers, asynchronous on the engine's stream. */
+int qmc_evaluate_dev(qmc_engine *eng, int64_t nconf, const double *pos_dev,
+                     double *wf_dev, double *energy_dev, double *ith_dev,
+                     double *drift_dev);
+
+/* ---- VMC ensemble of independent Metropolis chains -------------------- */
+/* vmc.Sampling + core_funcs.states_generator/blocks (qmc_base/vmc.py:557-648,
+ * 670-770; jastrow/vmc.py:169-264; mrbp_qmc/vmc.py:174-233). */
+int qmc_vmc_create(qmc_engine *eng, const qmc_vmc_params *p, qmc_vmc **out);
+void qmc_vmc_destroy(qmc_vmc *v);
+/* build_state (mrbp_qmc/vmc.py:145-165) for every chain: uploads pos[W][N],
+ * evaluates log|psi|, resets the step counter; the next block's first yield
+ * is the initial state flagged ACCEPTED (qmc_base/vmc.py:616-618). */
+int qmc_vmc_set_state(qmc_vmc *v, const double *pos);
+int qmc_vmc_get_state(qmc_vmc *v, double *pos, double *wf_abs_log,
+                      double *energy_carry);
+/* One block of `nyield` generator yields per chain.  Per-chain block sums
+ * (sum of energy, of energy^2, accepted count) are always produced on the
+ * device; the host copies requested here synchronise.  Series buffers are
+ * [nyield][W] (step-major) host arrays or NULL. */
+int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_energy,
+                      double *sum_energy2, int64_t *num_accepted,
+                      double *series_wf, double *series_energy,
+                      uint8_t *series_stat);
+/* Device addresses of the per-chain block sums of the last block
+ * (sum_e[W], sum_e2[W], n_acc[W]) for on-device reductions / collectives. */
+int qmc_vmc_block_sums_dev(qmc_vmc *v, double **sum_e, double **sum_e2,
+                           int64_t **n_acc);
+/* TEST ONLY: replay a recorded random stream instead of Philox.  tape is
+ * host [W][steps][N + 1] (N proposal draws, then the accept uniform). */
+int qmc_vmc_set_tape(qmc_vmc *v, const double *tape, int64_t steps);
+
+/* ---- DMC walker ensemble ---------------------------------------------- */
+/* dmc.Sampling + core_funcs.states_generator/blocks (qmc_base/dmc.py:614-787,
+ * 815-971; jastrow/dmc.py:634-951, 1030-1174; mrbp_qmc/dmc.py:268-328). */
+int qmc_dmc_create(qmc_engine *eng, const qmc_dmc_params *p, qmc_dmc **out);
+void qmc_dmc_destroy(qmc_dmc *d);
+/* build_state (mrbp_qmc/dmc.py:268-328): uploads pos[nw][N], computes energy
+ * and drift of every walker, unit weights; ref_energy = mean energy unless
+ * use_ref_energy.  The caller has already applied `[-target_num_walkers:]`. */
+int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
+                      int use_ref_energy, double ref_energy);
+/* Restart from a yielded State (qmc_base/dmc.py:707-716): confs[nw][2][N],
+ * energy[nw], weight[nw] copied as they are. */
+int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw, const double *confs,
+                           const double *energy, const double *weight,
+                           double ref_energy);
+/* `nsteps` generator iterations (branch -> diffuse/evaluate -> estimators ->
+ * E_ref feedback).  Per-step series are host arrays of length nsteps or NULL
+ * (PropsData, qmc_base/dmc.py:130-143). */
+int qmc_dmc_run_block(qmc_dmc *d, int64_t nsteps, double *energy,
+                      double *weight, uint64_t *num_walkers,
+                      double *ref_energy, double *accum_energy);
+/* The yielded ("actual") State after the last step (qmc_base/dmc.py:773-780):
+ * confs[maxw][2][N], energy/weight[maxw], mask[maxw], cloning_ref[maxw];
+ * scalars[5] = energy, weight, ref_energy, accum_energy, num_walkers. */
+int qmc_dmc_get_state(qmc_dmc *d, double *confs, double *energy,
+                      double *weight, uint8_t *mask, int64_t *cloning_ref,
+                      double *scalars);
+/* Split step for multi-GPU runs (external_reduce = 1): step_local runs the
+ * branching and propagation of this rank's walkers and leaves this rank's
+ * (E_t, W_t) in partial_dev[0..1]; the caller all-reduces them (RCCL) into
+ * total_dev[0..1] on the same stream; step_finish applies the E_ref feedback
+ * with the global sums and the global target. */
+int qmc_dmc_step_local(qmc_dmc *d, double *partial_dev);
+int qmc_dmc_step_finish(qmc_dmc *d, const double *total_dev);
+int qmc_dmc_read_series(qmc_dmc *d, int64_t nsteps, double *energy,
+                        double *weight, uint64_t *num_walkers,
+                        double *ref_energy, double *accum_energy);
+/* Population rebalance: pack walkers [first, first+count) of the current
+ * population into buf_dev[count][2N+2] (pos, drift, energy, weight) / append
+ * `count` packed walkers; truncate drops the tail. */
+int qmc_dmc_num_walkers(qmc_dmc *d, int64_t *nw);
+int qmc_dmc_export_walkers(qmc_dmc *d, int64_t first, int64_t count,
+                           double *buf_dev);
+int qmc_dmc_import_walkers(qmc_dmc *d, int64_t count, const double *buf_dev);
+int qmc_dmc_truncate(qmc_dmc *d, int64_t new_nw);
+/* TEST ONLY: replay recorded streams.  u[] / g[] are host arrays; step t
+ * reads its branching uniforms at u[u_off[t] + parent] and its standard
+ * normals at g[g_off[t] + slot*N + i]. */
+int qmc_dmc_set_tape(qmc_dmc *d, const double *u, int64_t nu, const double *g,
+                     int64_t ng, const int64_t *u_off, const int64_t *g_off,
+                     int64_t nsteps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1531 @@
+// qmcwalk.hip -- kernels and C-ABI of libqmcwalk.so (gfx950 / MI355X).
+// Interface: include/qmcwalk.h.  Device building blocks: qmc_device.h.
+//
+// HBM layout (all fp64, "slot-major"): a walker slot owns one contiguous row
+// of N positions and one of N drifts, pos[W][N] / drift[W][N]; the lane that
+// owns particle i of walker w reads pos[w][i], so a lane group loads its row
+// with one coalesced 8*G-byte access.  Per-walker scalars (energy, weight,
+// slot energy, parent index) are plain [W] arrays.  DMC keeps two such
+// population buffers (parents / children) that swap roles every time step.
+#include "qmc_device.h"
+#include "../../include/qmcwalk.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// --------------------------------------------------------------- errors ---
+static thread_local std::string g_err;
+
+static int fail(const std::string &msg)
+{
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess)                                                \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+extern "C" const char *qmc_last_error(void) { return g_err.c_str(); }
+extern "C" int qmc_abi_version(void) { return QMCWALK_ABI_VERSION; }
+extern "C" int qmc_device_count(int *count)
+{
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+// ------------------------------------------------------------- handles ----
+struct qmc_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevModel dm;
+    qmc_model_params mp;
+    int G = 64, P = 1;
+    bool pad = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
+
+static int pick_shape(int n, int &G, int &P, bool &pad)
+{
+    if (n < 1) return 1;
+    if (n <= 16) { G = 16; P = 1; }
+    else if (n <= 32) { G = 16; P = 2; }
+    else if (n <= 64) { G = 64; P = 1; }
+    else if (n <= 128) { G = 64; P = 2; }
+    else if (n <= 256) { G = 64; P = 4; }
+    else if (n <= 512) { G = 64; P = 8; }
+    else return 1;
+    pad = (n != G * P);
+    return 0;
+}
+
+// --------------------------------------------------------------- kernels ---
+struct EvalArgs {
+    const double *pos;   // [W][N]
+    double *wf, *energy; // [W]
+    double *ith, *drift; // [W][N]
+    long long nconf;
+};
+
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+evaluate_kernel(DevModel m, EvalArgs a)
+{
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;            // groups per block
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long w = (long long)blockIdx.x * GPB + grp;
+    const bool active = w < a.nconf;
+    const long long wr = active ? w : 0;
+    double z[P], F[P], ei[P], E, wf;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+    }
+    eval_walker<G, P, PAD, true, true, ZC>(m, z, gl, lds, F, ei, E, wf);
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < m.n) {
+            if (a.ith) a.ith[w * m.n + i] = ei[p];
+            if (a.drift) a.drift[w * m.n + i] = F[p];
+        }
+    }
+    if (gl == 0) {
+        if (a.wf) a.wf[w] = wf;
+        if (a.energy) a.energy[w] = E;
+    }
+}
+
+// Energy + drift only (no log|psi|, no per-particle energies): the DMC
+// build_state pass (qmc_base/jastrow/dmc.py:1043-1078).
+struct PrepArgs {
+    const double *pos;
+    double *drift, *energy;
+    long long nconf;
+};
+
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+prepare_kernel(DevModel m, PrepArgs a)
+{
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long w = (long long)blockIdx.x * GPB + grp;
+    const bool active = w < a.nconf;
+    const long long wr = active ? w : 0;
+    double z[P], F[P], ei[P], E, wf;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+    }
+    eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, E, wf);
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < m.n) a.drift[w * m.n + i] = F[p];
+    }
+    if (gl == 0) a.energy[w] = E;
+}
+
+// ---- VMC: one launch advances every chain by a whole block of yields ----
+struct VmcArgs {
+    double *pos;          // [W][N] in/out
+    double *wf;           // [W]    in/out  log|psi|
+    double *ecarry;       // [W]    in/out  energy carried to rejected moves
+    double *sum_e, *sum_e2;
+    long long *n_acc;
+    double *ser_wf, *ser_e;   // [nyield][W] or null
+    unsigned char *ser_stat;
+    const double *tape;   // [W][tape_steps][N+1] or null
+    long long tape_steps;
+    long long W;
+    long long nyield;
+    int yield_initial;
+    int gaussian;
+    unsigned int step0;
+    unsigned int chain0;
+    unsigned long long seed;
+    double move_spread;
+};
+
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+vmc_block_kernel(DevModel m, VmcArgs a)
+{
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long w = (long long)blockIdx.x * GPB + grp;
+    const bool active = w < a.W;
+    const long long wr = active ? w : 0;
+    const int n = m.n;
+
+    double z[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        z[p] = (i < n) ? a.pos[wr * n + i] : 0.0;
+    }
+    double wf_cur = a.wf[wr];
+    double e_cur = a.ecarry[wr];
+    double se = 0.0, se2 = 0.0;
+    long long nacc = 0;
+    unsigned int step = a.step0;
+    const unsigned int slot = a.chain0 + (unsigned int)wr;
+    long long treal = 0;      // real steps done in this launch (tape index)
+
+    for (long long y = 0; y < a.nyield; ++y) {
+        // The very first yield of a generator is the initial state itself,
+        // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
+        const bool forced = (y == 0) && a.yield_initial;
+        double zn[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int i = gl + G * p;
+            double d = 0.0;
+            if (!forced && i < n) {
+                if (a.tape) {
+                    double tv = a.tape[(wr * a.tape_steps + treal) * (n + 1) + i];
+                    d = a.gaussian ? a.move_spread * tv
+                                   : (tv - 0.5) * a.move_spread;
+                } else if (a.gaussian) {
+                    d = a.move_spread *
+                        philox_normal(a.seed, slot, step, (unsigned)i,
+                                      STREAM_VMC_MOVE);
+                } else {
+                    double u0, u1;
+                    philox_uniform2(a.seed, slot, step, (unsigned)i,
+                                    STREAM_VMC_MOVE, u0, u1);
+                    d = (u0 - 0.5) * a.move_spread;
+                }
+            }
+            // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
+            zn[p] = forced ? z[p] : wrap_box(z[p] + d, m.L);
+        }
+        double F[P], ei[P], e_new, wf_new;
+        eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
+                                                wf_new);
+        double ua = 1.0;
+        if (!forced) {
+            if (a.tape) {
+                ua = a.tape[(wr * a.tape_steps + treal) * (n + 1) + n];
+            } else {
+                double u1;
+                philox_uniform2(a.seed, slot, step, 0u, STREAM_VMC_ACCEPT, ua,
+                                u1);
+            }
+        }
+        // Metropolis test (qmc_base/vmc.py:636)
+        const bool acc = forced || (wf_new > 0.5 * log(ua) + wf_cur);
+        if (acc) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) z[p] = zn[p];
+            if (!forced) wf_cur = wf_new;
+            e_cur = e_new;   // energy only re-evaluated on accepted moves
+            ++nacc;          // (qmc_base/jastrow/vmc.py:253-262)
+        }
+        se += e_cur;
+        se2 += e_cur * e_cur;
+        if (active && gl == 0) {
+            if (a.ser_wf) a.ser_wf[y * a.W + w] = wf_cur;
+            if (a.ser_e) a.ser_e[y * a.W + w] = e_cur;
+            if (a.ser_stat) a.ser_stat[y * a.W + w] = acc ? 1 : 0;
+        }
+        if (!forced) { ++step; ++treal; }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < n) a.pos[w * n + i] = z[p];
+    }
+    if (gl == 0) {
+        a.wf[w] = wf_cur;
+        a.ecarry[w] = e_cur;
+        a.sum_e[w] = se;
+        a.sum_e2[w] = se2;
+        a.n_acc[w] = nacc;
+    }
+}
+
+// ---- DMC ---------------------------------------------------------------
+// Device-resident control block of a DMC ensemble.
+struct DmcCtl {
+    long long prev_nw;      // walkers in the parent buffer
+    long long nw;           // walkers after branching (this step)
+    double ref_energy;
+    double total_energy, total_weight;
+    double e_t, w_t;        // estimators of this step (local or global)
+    unsigned int step;
+    unsigned int pad;
+};
+
+struct BranchArgs {
+    const double *weight;     // parent weights [maxw]
+    const double *energy;     // parent energies [maxw]
+    int *count;               // clone counts [maxw]
+    long long *block_tot;     // [nblocks]
+    long long *block_off;     // [nblocks]
+    double *block_esum;       // [nblocks] partial sums of parent energies
+    long long *ref;           // cloning table [maxw]
+    DmcCtl *ctl;
+    const double *u_tape;     // uniforms of this step or null
+    long long maxw;
+    unsigned long long seed;
+    unsigned int slot0;
+};
+
+static constexpr int BR_ITEMS = 4;                    // parents per thread
+static constexpr int BR_TILE = BLOCK * BR_ITEMS;      // parents per block
+
+// Clone counts c_s = int(w_s + u_s) (qmc_base/dmc.py:641-642) + block totals.
+__global__ void __launch_bounds__(BLOCK) branch_count_kernel(BranchArgs a)
+{
+    __shared__ long long red[BLOCK / 64];
+    const long long prev_nw = a.ctl->prev_nw;
+    const unsigned int step = a.ctl->step;
+    long long base = (long long)blockIdx.x * BR_TILE + threadIdx.x * BR_ITEMS;
+    long long tot = 0;
+#pragma unroll
+    for (int k = 0; k < BR_ITEMS; ++k) {
+        long long s = base + k;
+        int c = 0;
+        if (s < prev_nw) {
+            double u, u1;
+            if (a.u_tape) u = a.u_tape[s];
+            else philox_uniform2(a.seed, a.slot0 + (unsigned)s, step, 0u,
+                                 STREAM_DMC_BRANCH, u, u1);
+            c = (int)(a.weight[s] + u);
+            a.count[s] = c;
+        }
+        tot += c;
+    }
+    for (int msk = 1; msk < 64; msk <<= 1)
+        tot += __shfl_xor(tot, msk, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int i = 0; i < BLOCK / 64; ++i) t += red[i];
+        a.block_tot[blockIdx.x] = t;
+    }
+}
+
+// Exclusive scan of the block totals (single workgroup, serial over chunks;
+// at most maxw / 1024 entries) and the capped population size
+// (qmc_base/dmc.py:638-653).
+__global__ void __launch_bounds__(BLOCK)
+branch_scan_kernel(BranchArgs a, int nblocks)
+{
+    __shared__ long long sh[BLOCK];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const long long prev_nw = a.ctl->prev_nw;
+    const int used = (int)((prev_nw + BR_TILE - 1) / BR_TILE);
+    for (int base = 0; base < nblocks; base += BLOCK) {
+        int i = base + threadIdx.x;
+        long long v = (i < used) ? a.block_tot[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        // Hillis-Steele inclusive scan over BLOCK entries
+        for (int off = 1; off < BLOCK; off <<= 1) {
+            long long t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) a.block_off[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == BLOCK - 1) carry += sh[BLOCK - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long nw = carry < a.maxw ? carry : a.maxw;
+        a.ctl->nw = nw;
+    }
+}
+
+// Scatter parent indices into the cloning table in parent order, truncated at
+// max_num_walkers; per-block partial sums of the yielded energies
+// E_t = sum_s E_parent(ref[s]) (qmc_base/dmc.py:759-762).
+__global__ void __launch_bounds__(BLOCK) branch_scatter_kernel(BranchArgs a)
+{
+    __shared__ long long wtot[BLOCK / 64];
+    __shared__ double wsum[BLOCK / 64];
+    const long long prev_nw = a.ctl->prev_nw;
+    long long base = (long long)blockIdx.x * BR_TILE + threadIdx.x * BR_ITEMS;
+    int c[BR_ITEMS];
+    long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < BR_ITEMS; ++k) {
+        long long s = base + k;
+        c[k] = (s < prev_nw) ? a.count[s] : 0;
+        mine += c[k];
+    }
+    // exclusive scan of `mine` over the block
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        long long t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    long long woff = 0;
+    for (int i = 0; i < wv; ++i) woff += wtot[i];
+    long long off = a.block_off[blockIdx.x] + woff + incl - mine;
+    double esum = 0.0;
+#pragma unroll
+    for (int k = 0; k < BR_ITEMS; ++k) {
+        long long s = base + k;
+        long long lo = off, hi = off + c[k];
+        if (hi > a.maxw) hi = a.maxw;
+        for (long long t = lo; t < hi; ++t) a.ref[t] = s;
+        if (hi > lo) esum += (double)(hi - lo) * a.energy[s];
+        off += c[k];
+    }
+    for (int msk = 1; msk < 64; msk <<= 1)
+        esum += __shfl_xor(esum, msk, 64);
+    if (lane == 0) wsum[wv] = esum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < BLOCK / 64; ++i) t += wsum[i];
+        a.block_esum[blockIdx.x] = t;
+    }
+}
+
+// Sum the per-block energy partials in a fixed order -> this rank's E_t, W_t.
+__global__ void __launch_bounds__(BLOCK)
+dmc_local_sums_kernel(const double *block_esum, DmcCtl *ctl, double *partial)
+{
+    __shared__ double sh[BLOCK];
+    const long long prev_nw = ctl->prev_nw;
+    const int used = (int)((prev_nw + BR_TILE - 1) / BR_TILE);
+    double t = 0.0;
+    for (int i = threadIdx.x; i < used; i += BLOCK) t += block_esum[i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ctl->e_t = sh[0];
+        ctl->w_t = (double)ctl->nw;     // unit weights after branching
+        if (partial) { partial[0] = sh[0]; partial[1] = (double)ctl->nw; }
+    }
+}
+
+struct EvolveArgs {
+    const double *ppos, *pdrift, *penergy;   // parents
+    double *cpos, *cdrift, *cenergy, *cweight; // children
+    double *eslot;            // energy the slot held in the previous iteration
+    const long long *ref;
+    const DmcCtl *ctl;
+    const double *g_tape;     // [slot][N] standard normals or null
+    long long maxw;
+    double dt, sigma;
+    unsigned long long seed;
+    unsigned int slot0;
+    int fix_stale;
+};
+
+// Drift-diffusion + local energy of every child walker
+// (qmc_base/jastrow/dmc.py:758-825, 892-942).
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+dmc_evolve_kernel(DevModel m, EvolveArgs a)
+{
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long s = (long long)blockIdx.x * GPB + grp;
+    const long long nw = a.ctl->nw;
+    // whole block beyond the population: nothing to do
+    if ((long long)blockIdx.x * GPB >= nw) return;
+    const bool active = s < nw;
+    const long long sr = active ? s : 0;
+    const int n = m.n;
+    const unsigned int step = a.ctl->step;
+    const double ref_energy = a.ctl->ref_energy;
+    const long long par = a.ref[sr];
+
+    double z[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        double zz = 0.0;
+        if (i < n) {
+            double z0 = a.ppos[par * n + i];
+            double f0 = a.pdrift[par * n + i];
+            double g = a.g_tape ? a.g_tape[sr * n + i]
+                                : philox_normal(a.seed, a.slot0 + (unsigned)sr,
+                                                step, (unsigned)i,
+                                                STREAM_DMC_DIFFUSE);
+            // ith_diffusion (qmc_base/jastrow/dmc.py:661-671)
+            double zn = z0 + 2 * f0 * a.dt + a.sigma * g;
+            zz = wrap_box(zn, m.L);
+        }
+        z[p] = zz;
+    }
+    double F[P], ei[P], e_next, wf;
+    eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, e_next, wf);
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < n) {
+            a.cpos[s * n + i] = z[p];
+            a.cdrift[s * n + i] = F[p];
+        }
+    }
+    if (gl == 0) {
+        double e_par = a.penergy[par];
+        // the reference averages with the energy slot s held in
+        // the previous iteration (jastrow/dmc.py:810), not the parent's.
+        double e_old = a.fix_stale ? e_par : a.eslot[s];
+        double mean_energy = (e_next + e_old) / 2;
+        a.cenergy[s] = e_next;
+        a.cweight[s] = exp(-a.dt * (mean_energy - ref_energy));
+        a.eslot[s] = e_par;
+    }
+}
+
+struct FinishArgs {
+    DmcCtl *ctl;
+    const double *total;      // global (E_t, W_t) or null -> local values
+    double *ser_e, *ser_w, *ser_ref, *ser_acc;
+    unsigned long long *ser_nw;
+    long long ser_idx;
+    double kappa, dt, target;
+};
+
+// E_ref feedback (qmc_base/dmc.py:759-785) + per-step series.
+__global__ void dmc_finish_kernel(FinishArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DmcCtl *c = a.ctl;
+    double e_t = a.total ? a.total[0] : c->e_t;
+    double w_t = a.total ? a.total[1] : c->w_t;
+    c->total_energy += e_t;
+    c->total_weight += w_t;
+    double accum = c->total_energy / c->total_weight;
+    double ref = accum - a.kappa * log(w_t / a.target) / a.dt;
+    c->ref_energy = ref;
+    c->e_t = e_t;
+    c->w_t = w_t;
+    if (a.ser_e) {
+        a.ser_e[a.ser_idx] = e_t;
+        a.ser_w[a.ser_idx] = w_t;
+        a.ser_nw[a.ser_idx] = (unsigned long long)c->nw;
+        a.ser_ref[a.ser_idx] = ref;
+        a.ser_acc[a.ser_idx] = accum;
+    }
+    c->prev_nw = c->nw;
+    c->step += 1;
+}
+
+// Gather the yielded ("actual") configurations: confs[s] = parents[ref[s]].
+__global__ void dmc_gather_state_kernel(const double *ppos,
+                                        const double *pdrift,
+                                        const long long *ref, long long nw,
+                                        int n, double *confs)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nw * n) return;
+    long long s = idx / n;
+    int i = (int)(idx % n);
+    long long p = ref[s];
+    confs[(s * 2 + 0) * n + i] = ppos[p * n + i];
+    confs[(s * 2 + 1) * n + i] = pdrift[p * n + i];
+}
+
+__global__ void pack_walkers_kernel(const double *pos, const double *drift,
+                                    const double *energy, const double *weight,
+                                    long long first, long long count, int n,
+                                    double *buf)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int rec = 2 * n + 2;
+    if (idx >= count * rec) return;
+    long long s = idx / rec;
+    int j = (int)(idx % rec);
+    long long src = first + s;
+    double v;
+    if (j < n) v = pos[src * n + j];
+    else if (j < 2 * n) v = drift[src * n + (j - n)];
+    else if (j == 2 * n) v = energy[src];
+    else v = weight[src];
+    buf[idx] = v;
+}
+
+__global__ void unpack_walkers_kernel(double *pos, double *drift,
+                                      double *energy, double *weight,
+                                      long long first, long long count, int n,
+                                      const double *buf)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int rec = 2 * n + 2;
+    if (idx >= count * rec) return;
+    long long s = idx / rec;
+    int j = (int)(idx % rec);
+    long long dst = first + s;
+    double v = buf[idx];
+    if (j < n) pos[dst * n + j] = v;
+    else if (j < 2 * n) drift[dst * n + (j - n)] = v;
+    else if (j == 2 * n) energy[dst] = v;
+    else weight[dst] = v;
+}
+
+// ------------------------------------------------------------ dispatch ----
+template <template <int, int, bool, bool> class L, typename... A>
+static int dispatch_shape(const qmc_engine *e, A &&...args)
+{
+    const bool zc = e->dm.zclass != 0;
+#define QMC_CASE(g, p)                                                        \
+    if (e->G == g && e->P == p) {                                             \
+        if (e->pad) {                                                         \
+            if (zc) return L<g, p, true, true>::run(e, args...);              \
+            return L<g, p, true, false>::run(e, args...);                     \
+        }                                                                     \
+        if (zc) return L<g, p, false, true>::run(e, args...);                 \
+        return L<g, p, false, false>::run(e, args...);                        \
+    }
+    QMC_CASE(16, 1) QMC_CASE(16, 2) QMC_CASE(64, 1) QMC_CASE(64, 2)
+    QMC_CASE(64, 4) QMC_CASE(64, 8)
+#undef QMC_CASE
+    return fail("unsupported boson_number");
+}
+
+template <int G, int P, bool ZC>
+static size_t lds_bytes()
+{
+    return (size_t)(BLOCK / G) * GroupLds<G, P, ZC>::DOUBLES * sizeof(double);
+}
+
+// Dynamic LDS above the default limit must be opted into per kernel.
+template <typename K>
+static void allow_lds(K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+}
+
+template <int G>
+static unsigned grid_for(long long nwalkers)
+{
+    const long long gpb = BLOCK / G;
+    return (unsigned)((nwalkers + gpb - 1) / gpb);
+}
+
+template <int G, int P, bool PAD, bool ZC>
+struct LaunchEval {
+    static int run(const qmc_engine *e, const EvalArgs &a)
+    {
+        if (a.nconf <= 0) return 0;
+        const size_t lds = lds_bytes<G, P, ZC>();
+        allow_lds(evaluate_kernel<G, P, PAD, ZC>, lds);
+        hipLaunchKernelGGL((evaluate_kernel<G, P, PAD, ZC>),
+                           dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                           lds, e->stream, e->dm, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+};
+
+template <int G, int P, bool PAD, bool ZC>
+struct LaunchPrep {
+    static int run(const qmc_engine *e, const PrepArgs &a)
+    {
+        if (a.nconf <= 0) return 0;
+        const size_t lds = lds_bytes<G, P, ZC>();
+        allow_lds(prepare_kernel<G, P, PAD, ZC>, lds);
+        hipLaunchKernelGGL((prepare_kernel<G, P, PAD, ZC>),
+                           dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                           lds, e->stream, e->dm, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+};
+
+template <int G, int P, bool PAD, bool ZC>
+struct LaunchVmc {
+    static int run(const qmc_engine *e, const VmcArgs &a)
+    {
+        const size_t lds = lds_bytes<G, P, ZC>();
+        allow_lds(vmc_block_kernel<G, P, PAD, ZC>, lds);
+        hipLaunchKernelGGL((vmc_block_kernel<G, P, PAD, ZC>),
+                           dim3(grid_for<G>(a.W)), dim3(BLOCK),
+                           lds, e->stream, e->dm, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+};
+
+template <int G, int P, bool PAD, bool ZC>
+struct LaunchEvolve {
+    static int run(const qmc_engine *e, const EvolveArgs &a)
+    {
+        const size_t lds = lds_bytes<G, P, ZC>();
+        allow_lds(dmc_evolve_kernel<G, P, PAD, ZC>, lds);
+        hipLaunchKernelGGL((dmc_evolve_kernel<G, P, PAD, ZC>),
+                           dim3(grid_for<G>(a.maxw)), dim3(BLOCK),
+                           lds, e->stream, e->dm, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+};
+
+// -------------------------------------------------------------- engine ----
+static void build_dev_model(const qmc_model_params &p, DevModel &d)
+{
+    memset(&d, 0, sizeof(d));
+    d.n = (int)p.boson_number;
+    d.is_free = p.is_free != 0;
+    d.is_ideal = p.is_ideal != 0;
+    d.defects_sep = (int)(p.defects_sep > 0 ? p.defects_sep : 1);
+    d.L = p.supercell_size;
+    d.half_L = 0.5 * d.L;
+    d.rm = fabs(p.tbf_contact_cutoff);
+    d.L_minus_rm = d.L - d.rm;
+    d.pi_L = QMC_PI / d.L;
+    d.k2 = p.param_k2;
+    d.k2sq = d.k2 * d.k2;
+    double phi = p.param_k2 * p.param_r_off;
+    d.cphi = cos(phi);
+    d.sphi = sin(phi);
+    double th = p.param_k2 * d.L;
+    d.cth = cos(th);
+    d.sth = sin(th);
+    d.sin_rm = (d.rm >= d.half_L) ? 1.0 : sin(QMC_PI * d.rm / d.L);
+    // sin(pi r / L) is flat near r = L/2: classify from positions there
+    d.zclass = d.rm > 0.45 * d.L;
+    d.a_long = d.pi_L * p.param_beta;
+    d.b_long = d.pi_L * d.pi_L * p.param_beta;
+    d.beta = p.param_beta;
+    d.log_am = log(fabs(p.param_am));
+    d.z_a = 1.0 / (1.0 + p.lattice_ratio);
+    d.z_b = p.lattice_ratio / (1.0 + p.lattice_ratio);
+    d.k1 = p.param_k1;
+    d.kp1 = p.param_kp1;
+    d.e0 = p.param_e0;
+    d.v0 = p.lattice_depth;
+    d.v0d = p.defect_magnitude;
+    d.v0_minus_e0 = p.lattice_depth - p.param_e0;
+    if (!d.is_free) {
+        double sh = sinh(0.5 * sqrt(d.v0 - d.e0) * d.z_b);
+        d.cf = sqrt(1 + d.v0 / d.e0 * sh * sh);
+    } else {
+        d.cf = 1.0;
+    }
+}
+
+extern "C" int qmc_engine_create(const qmc_model_params *model, int device,
+                                 void *stream, qmc_engine **out)
+{
+    if (!model || !out) return fail("qmc_engine_create: null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("qmc_engine_create: no HIP device");
+    if (device < 0 || device >= ndev)
+        return fail("qmc_engine_create: bad device index");
+    qmc_engine *e = new qmc_engine();
+    e->device = device;
+    e->mp = *model;
+    if (pick_shape((int)model->boson_number, e->G, e->P, e->pad)) {
+        delete e;
+        return fail("qmc_engine_create: boson_number must be in [1, 512]");
+    }
+    build_dev_model(*model, e->dm);
+    HIP_TRY(hipSetDevice(device));
+    if (stream) {
+        e->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    HIP_TRY(hipEventCreate(&e->ev0));
+    HIP_TRY(hipEventCreate(&e->ev1));
+    *out = e;
+    return 0;
+}
+
+extern "C" void qmc_engine_destroy(qmc_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int qmc_engine_sync(qmc_engine *e)
+{
+    if (!e) return fail("null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int qmc_engine_timer_start(qmc_engine *e)
+{
+    if (!e) return fail("null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    return 0;
+}
+
+extern "C" int qmc_engine_timer_stop(qmc_engine *e, float *ms)
+{
+    if (!e || !ms) return fail("null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return 0;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+    return 0;
+}
+
+extern "C" int qmc_evaluate_dev(qmc_engine *e, int64_t nconf,
+                                const double *pos, double *wf, double *energy,
+                                double *ith, double *drift)
+{
+    if (!e || !pos) return fail("qmc_evaluate_dev: null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    EvalArgs a{ pos, wf, energy, ith, drift, (long long)nconf };
+    return dispatch_shape<LaunchEval>(e, a);
+}
+
+extern "C" int qmc_evaluate(qmc_engine *e, int64_t nconf, const double *pos,
+                            double *wf, double *energy, double *ith,
+                            double *drift)
+{
+    if (!e || !pos) return fail("qmc_evaluate: null argument");
+    if (nconf <= 0) return 0;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)e->dm.n, W = (size_t)nconf;
+    double *dpos, *dwf, *den, *dith, *ddr;
+    if (dev_alloc(&dpos, W * n) || dev_alloc(&dwf, W) || dev_alloc(&den, W) ||
+        dev_alloc(&dith, W * n) || dev_alloc(&ddr, W * n))
+        return 1;
+    HIP_TRY(hipMemcpyAsync(dpos, pos, W * n * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    int rc = qmc_evaluate_dev(e, nconf, dpos, dwf, den, dith, ddr);
+    if (!rc) {
+        if (wf) HIP_TRY(hipMemcpyAsync(wf, dwf, W * sizeof(double),
+                                       hipMemcpyDeviceToHost, e->stream));
+        if (energy) HIP_TRY(hipMemcpyAsync(energy, den, W * sizeof(double),
+                                           hipMemcpyDeviceToHost, e->stream));
+        if (ith) HIP_TRY(hipMemcpyAsync(ith, dith, W * n * sizeof(double),
+                                        hipMemcpyDeviceToHost, e->stream));
+        if (drift) HIP_TRY(hipMemcpyAsync(drift, ddr, W * n * sizeof(double),
+                                          hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    hipFree(dpos); hipFree(dwf); hipFree(den); hipFree(dith); hipFree(ddr);
+    return rc;
+}
+
+// ----------------------------------------------------------------- VMC ----
+struct qmc_vmc {
+    qmc_engine *eng = nullptr;
+    qmc_vmc_params p;
+    long long W = 0;
+    double *pos = nullptr, *wf = nullptr, *ecarry = nullptr;
+    double *sum_e = nullptr, *sum_e2 = nullptr;
+    long long *n_acc = nullptr;
+    double *tape = nullptr;
+    long long tape_steps = 0, tape_used = 0;
+    unsigned int step = 0;
+    int yield_initial = 1;
+};
+
+extern "C" int qmc_vmc_create(qmc_engine *e, const qmc_vmc_params *p,
+                              qmc_vmc **out)
+{
+    if (!e || !p || !out) return fail("qmc_vmc_create: null argument");
+    if (p->num_chains <= 0) return fail("qmc_vmc_create: num_chains <= 0");
+    HIP_TRY(hipSetDevice(e->device));
+    qmc_vmc *v = new qmc_vmc();
+    v->eng = e;
+    v->p = *p;
+    v->W = p->num_chains;
+    const size_t W = (size_t)v->W, n = (size_t)e->dm.n;
+    if (dev_alloc(&v->pos, W * n) || dev_alloc(&v->wf, W) ||
+        dev_alloc(&v->ecarry, W) || dev_alloc(&v->sum_e, W) ||
+        dev_alloc(&v->sum_e2, W) || dev_alloc(&v->n_acc, W)) {
+        delete v;
+        return 1;
+    }
+    *out = v;
+    return 0;
+}
+
+extern "C" void qmc_vmc_destroy(qmc_vmc *v)
+{
+    if (!v) return;
+    hipSetDevice(v->eng->device);
+    hipFree(v->pos); hipFree(v->wf); hipFree(v->ecarry);
+    hipFree(v->sum_e); hipFree(v->sum_e2); hipFree(v->n_acc);
+    if (v->tape) hipFree(v->tape);
+    delete v;
+}
+
+extern "C" int qmc_vmc_set_state(qmc_vmc *v, const double *pos)
+{
+    if (!v || !pos) return fail("qmc_vmc_set_state: null argument");
+    qmc_engine *e = v->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t W = (size_t)v->W, n = (size_t)e->dm.n;
+    HIP_TRY(hipMemcpyAsync(v->pos, pos, W * n * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(v->ecarry, 0, W * sizeof(double), e->stream));
+    int rc = qmc_evaluate_dev(e, v->W, v->pos, v->wf, nullptr, nullptr,
+                              nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    v->step = 0;
+    v->yield_initial = 1;
+    v->tape_used = 0;
+    return 0;
+}
+
+extern "C" int qmc_vmc_get_state(qmc_vmc *v, double *pos, double *wf,
+                                 double *ecarry)
+{
+    if (!v) return fail("qmc_vmc_get_state: null argument");
+    qmc_engine *e = v->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t W = (size_t)v->W, n = (size_t)e->dm.n;
+    if (pos) HIP_TRY(hipMemcpyAsync(pos, v->pos, W * n * sizeof(double),
+                                    hipMemcpyDeviceToHost, e->stream));
+    if (wf) HIP_TRY(hipMemcpyAsync(wf, v->wf, W * sizeof(double),
+                                   hipMemcpyDeviceToHost, e->stream));
+    if (ecarry) HIP_TRY(hipMemcpyAsync(ecarry, v->ecarry, W * sizeof(double),
+                                       hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int qmc_vmc_set_tape(qmc_vmc *v, const double *tape, int64_t steps)
+{
+    if (!v) return fail("qmc_vmc_set_tape: null argument");
+    qmc_engine *e = v->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    if (v->tape) { hipFree(v->tape); v->tape = nullptr; }
+    v->tape_steps = 0;
+    v->tape_used = 0;
+    if (!tape || steps <= 0) return 0;
+    size_t cnt = (size_t)v->W * (size_t)steps * (size_t)(e->dm.n + 1);
+    if (dev_alloc(&v->tape, cnt)) return 1;
+    HIP_TRY(hipMemcpy(v->tape, tape, cnt * sizeof(double),
+                      hipMemcpyHostToDevice));
+    v->tape_steps = steps;
+    return 0;
+}
+
+extern "C" int qmc_vmc_block_sums_dev(qmc_vmc *v, double **se, double **se2,
+                                      int64_t **na)
+{
+    if (!v) return fail("null argument");
+    if (se) *se = v->sum_e;
+    if (se2) *se2 = v->sum_e2;
+    if (na) *na = (int64_t *)v->n_acc;
+    return 0;
+}
+
+extern "C" int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_e,
+                                 double *sum_e2, int64_t *n_acc,
+                                 double *ser_wf, double *ser_e,
+                                 uint8_t *ser_stat)
+{
+    if (!v) return fail("qmc_vmc_run_block: null argument");
+    if (nyield <= 0) return fail("qmc_vmc_run_block: nyield must be >= 1");
+    qmc_engine *e = v->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t W = (size_t)v->W, ny = (size_t)nyield;
+    const long long real = nyield - (v->yield_initial ? 1 : 0);
+    if (v->tape && v->tape_used + real > v->tape_steps)
+        return fail("qmc_vmc_run_block: tape exhausted");
+    double *dwf = nullptr, *de = nullptr;
+    unsigned char *dst = nullptr;
+    if (ser_wf && dev_alloc(&dwf, ny * W)) return 1;
+    if (ser_e && dev_alloc(&de, ny * W)) return 1;
+    if (ser_stat && dev_alloc(&dst, ny * W)) return 1;
+    VmcArgs a;
+    a.pos = v->pos; a.wf = v->wf; a.ecarry = v->ecarry;
+    a.sum_e = v->sum_e; a.sum_e2 = v->sum_e2; a.n_acc = v->n_acc;
+    a.ser_wf = dwf; a.ser_e = de; a.ser_stat = dst;
+    a.tape = v->tape ? v->tape + (size_t)v->tape_used * (e->dm.n + 1) : nullptr;
+    a.tape_steps = v->tape_steps;
+    a.W = v->W; a.nyield = nyield;
+    a.yield_initial = v->yield_initial;
+    a.gaussian = v->p.gaussian;
+    a.step0 = v->step; a.chain0 = v->p.chain0;
+    a.seed = v->p.rng_seed; a.move_spread = v->p.move_spread;
+    int rc = dispatch_shape<LaunchVmc>(e, a);
+    if (rc) return rc;
+    v->step += (unsigned int)real;
+    v->tape_used += real;
+    v->yield_initial = 0;
+    bool need_sync = false;
+    if (sum_e) { HIP_TRY(hipMemcpyAsync(sum_e, v->sum_e, W * sizeof(double),
+                 hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (sum_e2) { HIP_TRY(hipMemcpyAsync(sum_e2, v->sum_e2, W * sizeof(double),
+                  hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (n_acc) { HIP_TRY(hipMemcpyAsync(n_acc, v->n_acc, W * sizeof(int64_t),
+                 hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (ser_wf) { HIP_TRY(hipMemcpyAsync(ser_wf, dwf, ny * W * sizeof(double),
+                  hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (ser_e) { HIP_TRY(hipMemcpyAsync(ser_e, de, ny * W * sizeof(double),
+                 hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (ser_stat) { HIP_TRY(hipMemcpyAsync(ser_stat, dst, ny * W,
+                    hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (need_sync) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (dwf) hipFree(dwf);
+    if (de) hipFree(de);
+    if (dst) hipFree(dst);
+    return 0;
+}
+
+// ----------------------------------------------------------------- DMC ----
+struct qmc_dmc {
+    qmc_engine *eng = nullptr;
+    qmc_dmc_params p;
+    long long maxw = 0;
+    int nblocks = 0;
+    // two population buffers: [0]/[1] alternate parent / child roles
+    double *pos[2] = { nullptr, nullptr }, *drift[2] = { nullptr, nullptr };
+    double *energy[2] = { nullptr, nullptr }, *weight[2] = { nullptr, nullptr };
+    int cur = 0;                 // index of the parent buffer
+    double *eslot = nullptr;
+    long long *ref = nullptr;
+    int *count = nullptr;
+    long long *block_tot = nullptr, *block_off = nullptr;
+    double *block_esum = nullptr;
+    DmcCtl *ctl = nullptr;
+    // per-step series (device), capacity ser_cap steps
+    double *ser_e = nullptr, *ser_w = nullptr, *ser_ref = nullptr,
+           *ser_acc = nullptr;
+    unsigned long long *ser_nw = nullptr;
+    long long ser_cap = 0, ser_len = 0;
+    // tapes (test only)
+    double *u_tape = nullptr, *g_tape = nullptr;
+    std::vector<long long> u_off, g_off;
+    long long tape_step = 0;
+    bool stepped = false;        // a step has run since the last set_state
+    double global_target = 0.0;
+};
+
+static int dmc_reserve_series(qmc_dmc *d, long long nsteps)
+{
+    if (nsteps <= d->ser_cap) return 0;
+    if (d->ser_e) { hipFree(d->ser_e); hipFree(d->ser_w); hipFree(d->ser_ref);
+                    hipFree(d->ser_acc); hipFree(d->ser_nw); }
+    if (dev_alloc(&d->ser_e, nsteps) || dev_alloc(&d->ser_w, nsteps) ||
+        dev_alloc(&d->ser_ref, nsteps) || dev_alloc(&d->ser_acc, nsteps) ||
+        dev_alloc(&d->ser_nw, nsteps))
+        return 1;
+    d->ser_cap = nsteps;
+    return 0;
+}
+
+extern "C" int qmc_dmc_create(qmc_engine *e, const qmc_dmc_params *p,
+                              qmc_dmc **out)
+{
+    if (!e || !p || !out) return fail("qmc_dmc_create: null argument");
+    if (p->max_num_walkers <= 0 || p->target_num_walkers <= 0)
+        return fail("qmc_dmc_create: walker counts must be positive");
+    if (!(p->time_step > 0)) return fail("qmc_dmc_create: time_step <= 0");
+    HIP_TRY(hipSetDevice(e->device));
+    qmc_dmc *d = new qmc_dmc();
+    d->eng = e;
+    d->p = *p;
+    d->maxw = p->max_num_walkers;
+    d->nblocks = (int)((d->maxw + BR_TILE - 1) / BR_TILE);
+    d->global_target = (double)p->target_num_walkers;
+    const size_t W = (size_t)d->maxw, n = (size_t)e->dm.n;
+    int rc = 0;
+    for (int b = 0; b < 2 && !rc; ++b) {
+        rc |= dev_alloc(&d->pos[b], W * n) || dev_alloc(&d->drift[b], W * n) ||
+              dev_alloc(&d->energy[b], W) || dev_alloc(&d->weight[b], W);
+    }
+    rc = rc || dev_alloc(&d->eslot, W) || dev_alloc(&d->ref, W) ||
+         dev_alloc(&d->count, W) || dev_alloc(&d->block_tot, d->nblocks) ||
+         dev_alloc(&d->block_off, d->nblocks) ||
+         dev_alloc(&d->block_esum, d->nblocks) || dev_alloc(&d->ctl, 1);
+    if (rc) { delete d; return 1; }
+    HIP_TRY(hipMemset(d->ctl, 0, sizeof(DmcCtl)));
+    HIP_TRY(hipMemset(d->ref, 0, W * sizeof(long long)));
+    HIP_TRY(hipMemset(d->eslot, 0, W * sizeof(double)));
+    *out = d;
+    return 0;
+}
+
+extern "C" void qmc_dmc_destroy(qmc_dmc *d)
+{
+    if (!d) return;
+    hipSetDevice(d->eng->device);
+    for (int b = 0; b < 2; ++b) {
+        hipFree(d->pos[b]); hipFree(d->drift[b]);
+        hipFree(d->energy[b]); hipFree(d->weight[b]);
+    }
+    hipFree(d->eslot); hipFree(d->ref); hipFree(d->count);
+    hipFree(d->block_tot); hipFree(d->block_off); hipFree(d->block_esum);
+    hipFree(d->ctl);
+    if (d->ser_e) { hipFree(d->ser_e); hipFree(d->ser_w); hipFree(d->ser_ref);
+                    hipFree(d->ser_acc); hipFree(d->ser_nw); }
+    if (d->u_tape) hipFree(d->u_tape);
+    if (d->g_tape) hipFree(d->g_tape);
+    delete d;
+}
+
+static int dmc_reset_ctl(qmc_dmc *d, long long nw, double ref_energy)
+{
+    DmcCtl c;
+    memset(&c, 0, sizeof(c));
+    c.prev_nw = nw;
+    c.nw = nw;
+    c.ref_energy = ref_energy;
+    HIP_TRY(hipMemcpyAsync(d->ctl, &c, sizeof(c), hipMemcpyHostToDevice,
+                           d->eng->stream));
+    HIP_TRY(hipStreamSynchronize(d->eng->stream));
+    d->cur = 0;
+    d->stepped = false;
+    d->tape_step = 0;
+    d->ser_len = 0;
+    return 0;
+}
+
+extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
+                                 int use_ref, double ref_energy)
+{
+    if (!d || !pos) return fail("qmc_dmc_set_state: null argument");
+    if (nw <= 0 || nw > d->maxw)
+        return fail("qmc_dmc_set_state: number of walkers out of range");
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMemsetAsync(d->pos[b], 0, W * n * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->drift[b], 0, W * n * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->energy[b], 0, W * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->weight[b], 0, W * sizeof(double), e->stream));
+    }
+    HIP_TRY(hipMemsetAsync(d->eslot, 0, W * sizeof(double), e->stream));
+    HIP_TRY(hipMemcpyAsync(d->pos[0], pos, (size_t)nw * n * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    PrepArgs a{ d->pos[0], d->drift[0], d->energy[0], (long long)nw };
+    int rc = dispatch_shape<LaunchPrep>(e, a);
+    if (rc) return rc;
+    std::vector<double> ones((size_t)nw, 1.0), en((size_t)nw);
+    HIP_TRY(hipMemcpyAsync(d->weight[0], ones.data(), (size_t)nw * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(en.data(), d->energy[0], (size_t)nw * sizeof(double),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(d->eslot, d->energy[0], (size_t)nw * sizeof(double),
+                           hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!use_ref) {
+        // mrbp_qmc/dmc.py:302-312: sum(E w) / sum(w) with unit weights
+        double se = 0.0;
+        for (size_t i = 0; i < (size_t)nw; ++i) se += en[i] * 1.0;
+        ref_energy = se / (double)nw;
+    }
+    return dmc_reset_ctl(d, nw, ref_energy);
+}
+
+extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
+                                      const double *confs,
+                                      const double *energy,
+                                      const double *weight, double ref_energy)
+{
+    if (!d || !confs || !energy || !weight)
+        return fail("qmc_dmc_set_full_state: null argument");
+    if (nw <= 0 || nw > d->maxw)
+        return fail("qmc_dmc_set_full_state: number of walkers out of range");
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
+    std::vector<double> hp((size_t)nw * n), hd((size_t)nw * n);
+    for (size_t s = 0; s < (size_t)nw; ++s) {
+        memcpy(&hp[s * n], confs + (s * 2 + 0) * n, n * sizeof(double));
+        memcpy(&hd[s * n], confs + (s * 2 + 1) * n, n * sizeof(double));
+    }
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMemsetAsync(d->pos[b], 0, W * n * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->drift[b], 0, W * n * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->energy[b], 0, W * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->weight[b], 0, W * sizeof(double), e->stream));
+    }
+    HIP_TRY(hipMemsetAsync(d->eslot, 0, W * sizeof(double), e->stream));
+    HIP_TRY(hipMemcpyAsync(d->pos[0], hp.data(), hp.size() * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d->drift[0], hd.data(), hd.size() * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d->energy[0], energy, (size_t)nw * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d->weight[0], weight, (size_t)nw * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d->eslot, energy, (size_t)nw * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return dmc_reset_ctl(d, nw, ref_energy);
+}
+
+extern "C" int qmc_dmc_set_tape(qmc_dmc *d, const double *u, int64_t nu,
+                                const double *g, int64_t ng,
+                                const int64_t *u_off, const int64_t *g_off,
+                                int64_t nsteps)
+{
+    if (!d) return fail("qmc_dmc_set_tape: null argument");
+    HIP_TRY(hipSetDevice(d->eng->device));
+    if (d->u_tape) { hipFree(d->u_tape); d->u_tape = nullptr; }
+    if (d->g_tape) { hipFree(d->g_tape); d->g_tape = nullptr; }
+    d->u_off.clear(); d->g_off.clear();
+    d->tape_step = 0;
+    if (!u || !g || nsteps <= 0) return 0;
+    // pad so that a step may read up to maxw uniforms / maxw*N normals
+    size_t upad = (size_t)nu + (size_t)d->maxw;
+    size_t gpad = (size_t)ng + (size_t)d->maxw * (size_t)d->eng->dm.n;
+    if (dev_alloc(&d->u_tape, upad) || dev_alloc(&d->g_tape, gpad)) return 1;
+    HIP_TRY(hipMemset(d->u_tape, 0, upad * sizeof(double)));
+    HIP_TRY(hipMemset(d->g_tape, 0, gpad * sizeof(double)));
+    HIP_TRY(hipMemcpy(d->u_tape, u, (size_t)nu * sizeof(double),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->g_tape, g, (size_t)ng * sizeof(double),
+                      hipMemcpyHostToDevice));
+    d->u_off.assign(u_off, u_off + nsteps);
+    d->g_off.assign(g_off, g_off + nsteps);
+    return 0;
+}
+
+// Enqueue the rank-local part of one time step.
+static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev)
+{
+    qmc_engine *e = d->eng;
+    const int par = d->cur, chi = 1 - d->cur;
+    const double *ut = nullptr, *gt = nullptr;
+    if (d->u_tape) {
+        if (d->tape_step >= (long long)d->u_off.size())
+            return fail("qmc_dmc: tape exhausted");
+        ut = d->u_tape + d->u_off[(size_t)d->tape_step];
+        gt = d->g_tape + d->g_off[(size_t)d->tape_step];
+        d->tape_step += 1;
+    }
+    BranchArgs b;
+    b.weight = d->weight[par]; b.energy = d->energy[par];
+    b.count = d->count; b.block_tot = d->block_tot; b.block_off = d->block_off;
+    b.block_esum = d->block_esum; b.ref = d->ref; b.ctl = d->ctl;
+    b.u_tape = ut; b.maxw = d->maxw; b.seed = d->p.rng_seed;
+    b.slot0 = d->p.slot0;
+    hipLaunchKernelGGL(branch_count_kernel, dim3(d->nblocks), dim3(BLOCK), 0,
+                       e->stream, b);
+    hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(BLOCK), 0, e->stream,
+                       b, d->nblocks);
+    hipLaunchKernelGGL(branch_scatter_kernel, dim3(d->nblocks), dim3(BLOCK), 0,
+                       e->stream, b);
+    hipLaunchKernelGGL(dmc_local_sums_kernel, dim3(1), dim3(BLOCK), 0,
+                       e->stream, d->block_esum, d->ctl, partial_dev);
+    HIP_TRY(hipGetLastError());
+    EvolveArgs a;
+    a.ppos = d->pos[par]; a.pdrift = d->drift[par]; a.penergy = d->energy[par];
+    a.cpos = d->pos[chi]; a.cdrift = d->drift[chi];
+    a.cenergy = d->energy[chi]; a.cweight = d->weight[chi];
+    a.eslot = d->eslot; a.ref = d->ref; a.ctl = d->ctl; a.g_tape = gt;
+    a.maxw = d->maxw; a.dt = d->p.time_step;
+    a.sigma = sqrt(2 * d->p.time_step);           // mrbp_qmc/dmc.py:178
+    a.seed = d->p.rng_seed; a.slot0 = d->p.slot0;
+    a.fix_stale = d->p.fix_stale_energy;
+    int rc = dispatch_shape<LaunchEvolve>(e, a);
+    if (rc) return rc;
+    return 0;
+}
+
+static int dmc_enqueue_finish(qmc_dmc *d, const double *total_dev,
+                              long long ser_idx)
+{
+    qmc_engine *e = d->eng;
+    FinishArgs f;
+    f.ctl = d->ctl; f.total = total_dev;
+    const bool rec = ser_idx >= 0;
+    f.ser_e = rec ? d->ser_e : nullptr; f.ser_w = d->ser_w;
+    f.ser_ref = d->ser_ref; f.ser_acc = d->ser_acc; f.ser_nw = d->ser_nw;
+    f.ser_idx = ser_idx;
+    f.kappa = d->p.num_walkers_control_factor; f.dt = d->p.time_step;
+    f.target = d->global_target;
+    hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(64), 0, e->stream, f);
+    HIP_TRY(hipGetLastError());
+    d->cur = 1 - d->cur;          // children become the parents
+    d->stepped = true;
+    return 0;
+}
+
+extern "C" int qmc_dmc_read_series(qmc_dmc *d, int64_t nsteps, double *energy,
+                                   double *weight, uint64_t *num_walkers,
+                                   double *ref_energy, double *accum_energy)
+{
+    if (!d) return fail("qmc_dmc_read_series: null argument");
+    if (nsteps > d->ser_len) return fail("qmc_dmc_read_series: too many steps");
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t ns = (size_t)nsteps;
+    if (energy) HIP_TRY(hipMemcpyAsync(energy, d->ser_e, ns * 8,
+                                       hipMemcpyDeviceToHost, e->stream));
+    if (weight) HIP_TRY(hipMemcpyAsync(weight, d->ser_w, ns * 8,
+                                       hipMemcpyDeviceToHost, e->stream));
+    if (num_walkers) HIP_TRY(hipMemcpyAsync(num_walkers, d->ser_nw, ns * 8,
+                                            hipMemcpyDeviceToHost, e->stream));
+    if (ref_energy) HIP_TRY(hipMemcpyAsync(ref_energy, d->ser_ref, ns * 8,
+                                           hipMemcpyDeviceToHost, e->stream));
+    if (accum_energy) HIP_TRY(hipMemcpyAsync(accum_energy, d->ser_acc, ns * 8,
+                                             hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int qmc_dmc_run_block(qmc_dmc *d, int64_t nsteps, double *energy,
+                                 double *weight, uint64_t *num_walkers,
+                                 double *ref_energy, double *accum_energy)
+{
+    if (!d) return fail("qmc_dmc_run_block: null argument");
+    if (nsteps <= 0) return fail("qmc_dmc_run_block: nsteps must be >= 1");
+    if (d->p.external_reduce)
+        return fail("qmc_dmc_run_block: ensemble was created for "
+                    "external_reduce; drive it with step_local/step_finish");
+    HIP_TRY(hipSetDevice(d->eng->device));
+    if (dmc_reserve_series(d, nsteps)) return 1;
+    d->ser_len = 0;
+    for (long long t = 0; t < nsteps; ++t) {
+        int rc = dmc_enqueue_local(d, nullptr);
+        if (rc) return rc;
+        rc = dmc_enqueue_finish(d, nullptr, t);
+        if (rc) return rc;
+        d->ser_len = t + 1;
+    }
+    if (energy || weight || num_walkers || ref_energy || accum_energy)
+        return qmc_dmc_read_series(d, nsteps, energy, weight, num_walkers,
+                                   ref_energy, accum_energy);
+    return 0;
+}
+
+extern "C" int qmc_dmc_step_local(qmc_dmc *d, double *partial_dev)
+{
+    if (!d || !partial_dev) return fail("qmc_dmc_step_local: null argument");
+    HIP_TRY(hipSetDevice(d->eng->device));
+    return dmc_enqueue_local(d, partial_dev);
+}
+
+extern "C" int qmc_dmc_step_finish(qmc_dmc *d, const double *total_dev)
+{
+    if (!d || !total_dev) return fail("qmc_dmc_step_finish: null argument");
+    HIP_TRY(hipSetDevice(d->eng->device));
+    if (d->ser_len >= d->ser_cap) {
+        // grow geometrically, keeping what was recorded
+        long long ncap = d->ser_cap ? d->ser_cap * 2 : 1024;
+        double *oe = d->ser_e, *ow = d->ser_w, *orf = d->ser_ref,
+               *oa = d->ser_acc;
+        unsigned long long *on = d->ser_nw;
+        long long olen = d->ser_len;
+        d->ser_e = nullptr; d->ser_cap = 0;
+        if (dmc_reserve_series(d, ncap)) return 1;
+        if (oe) {
+            hipStream_t s = d->eng->stream;
+            HIP_TRY(hipMemcpyAsync(d->ser_e, oe, olen * 8, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d->ser_w, ow, olen * 8, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d->ser_ref, orf, olen * 8, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d->ser_acc, oa, olen * 8, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d->ser_nw, on, olen * 8, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            hipFree(oe); hipFree(ow); hipFree(orf); hipFree(oa); hipFree(on);
+        }
+    }
+    int rc = dmc_enqueue_finish(d, total_dev, d->ser_len);
+    if (rc) return rc;
+    d->ser_len += 1;
+    return 0;
+}
+
+extern "C" int qmc_dmc_num_walkers(qmc_dmc *d, int64_t *nw)
+{
+    if (!d || !nw) return fail("qmc_dmc_num_walkers: null argument");
+    HIP_TRY(hipSetDevice(d->eng->device));
+    DmcCtl c;
+    HIP_TRY(hipMemcpyAsync(&c, d->ctl, sizeof(c), hipMemcpyDeviceToHost,
+                           d->eng->stream));
+    HIP_TRY(hipStreamSynchronize(d->eng->stream));
+    *nw = c.prev_nw;
+    return 0;
+}
+
+extern "C" int qmc_dmc_get_state(qmc_dmc *d, double *confs, double *energy,
+                                 double *weight, uint8_t *mask,
+                                 int64_t *cloning_ref, double *scalars)
+{
+    if (!d) return fail("qmc_dmc_get_state: null argument");
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
+    DmcCtl c;
+    HIP_TRY(hipMemcpyAsync(&c, d->ctl, sizeof(c), hipMemcpyDeviceToHost,
+                           e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const long long nw = d->stepped ? c.nw : c.prev_nw;
+    std::vector<long long> href(W, 0);
+    if (d->stepped)
+        HIP_TRY(hipMemcpy(href.data(), d->ref, W * sizeof(long long),
+                          hipMemcpyDeviceToHost));
+    if (confs) {
+        memset(confs, 0, W * 2 * n * sizeof(double));
+        if (d->stepped) {
+            // yielded walkers are the parents selected by the cloning table;
+            // the parent buffer of the last step is the one that is not `cur`
+            const int par = 1 - d->cur;
+            double *tmp;
+            if (dev_alloc(&tmp, (size_t)nw * 2 * n)) return 1;
+            long long tot = nw * (long long)n;
+            hipLaunchKernelGGL(dmc_gather_state_kernel,
+                               dim3((unsigned)((tot + 255) / 256)), dim3(256),
+                               0, e->stream, d->pos[par], d->drift[par],
+                               d->ref, nw, (int)n, tmp);
+            HIP_TRY(hipMemcpyAsync(confs, tmp, (size_t)nw * 2 * n * 8,
+                                   hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            hipFree(tmp);
+        } else {
+            std::vector<double> hp((size_t)nw * n), hd((size_t)nw * n);
+            HIP_TRY(hipMemcpy(hp.data(), d->pos[d->cur], hp.size() * 8,
+                              hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(hd.data(), d->drift[d->cur], hd.size() * 8,
+                              hipMemcpyDeviceToHost));
+            for (size_t s = 0; s < (size_t)nw; ++s) {
+                memcpy(confs + (s * 2 + 0) * n, &hp[s * n], n * 8);
+                memcpy(confs + (s * 2 + 1) * n, &hd[s * n], n * 8);
+            }
+        }
+    }
+    if (energy) {
+        memset(energy, 0, W * sizeof(double));
+        // after a step eslot[s] holds the parent's energy (actual.energy)
+        HIP_TRY(hipMemcpy(energy, d->stepped ? d->eslot : d->energy[d->cur],
+                          (size_t)nw * 8, hipMemcpyDeviceToHost));
+    }
+    if (weight) {
+        for (size_t s = 0; s < W; ++s) weight[s] = s < (size_t)nw ? 1.0 : 0.0;
+        if (!d->stepped)
+            HIP_TRY(hipMemcpy(weight, d->weight[d->cur], (size_t)nw * 8,
+                              hipMemcpyDeviceToHost));
+    }
+    if (mask)
+        for (size_t s = 0; s < W; ++s) mask[s] = s < (size_t)nw ? 0 : 1;
+    if (cloning_ref)
+        for (size_t s = 0; s < W; ++s) cloning_ref[s] = (int64_t)href[s];
+    if (scalars) {
+        scalars[0] = c.e_t; scalars[1] = c.w_t; scalars[2] = c.ref_energy;
+        scalars[3] = c.total_weight != 0.0 ? c.total_energy / c.total_weight
+                                           : 0.0;
+        scalars[4] = (double)nw;
+    }
+    return 0;
+}
+
+extern "C" int qmc_dmc_export_walkers(qmc_dmc *d, int64_t first, int64_t count,
+                                      double *buf_dev)
+{
+    if (!d || !buf_dev) return fail("qmc_dmc_export_walkers: null argument");
+    if (count <= 0) return 0;
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const int n = e->dm.n;
+    long long tot = count * (long long)(2 * n + 2);
+    hipLaunchKernelGGL(pack_walkers_kernel, dim3((unsigned)((tot + 255) / 256)),
+                       dim3(256), 0, e->stream, d->pos[d->cur],
+                       d->drift[d->cur], d->energy[d->cur], d->weight[d->cur],
+                       (long long)first, (long long)count, n, buf_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int dmc_set_prev_nw(qmc_dmc *d, long long nw)
+{
+    // host-side patch of the control block (rebalance is a synchronising
+    // operation anyway)
+    DmcCtl c;
+    HIP_TRY(hipMemcpyAsync(&c, d->ctl, sizeof(c), hipMemcpyDeviceToHost,
+                           d->eng->stream));
+    HIP_TRY(hipStreamSynchronize(d->eng->stream));
+    c.prev_nw = nw;
+    HIP_TRY(hipMemcpyAsync(d->ctl, &c, sizeof(c), hipMemcpyHostToDevice,
+                           d->eng->stream));
+    HIP_TRY(hipStreamSynchronize(d->eng->stream));
+    return 0;
+}
+
+extern "C" int qmc_dmc_import_walkers(qmc_dmc *d, int64_t count,
+                                      const double *buf_dev)
+{
+    if (!d || !buf_dev) return fail("qmc_dmc_import_walkers: null argument");
+    if (count <= 0) return 0;
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    int64_t nw = 0;
+    int rc = qmc_dmc_num_walkers(d, &nw);
+    if (rc) return rc;
+    if (nw + count > d->maxw)
+        return fail("qmc_dmc_import_walkers: population would exceed "
+                    "max_num_walkers");
+    const int n = e->dm.n;
+    long long tot = count * (long long)(2 * n + 2);
+    hipLaunchKernelGGL(unpack_walkers_kernel,
+                       dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                       e->stream, d->pos[d->cur], d->drift[d->cur],
+                       d->energy[d->cur], d->weight[d->cur], (long long)nw,
+                       (long long)count, n, buf_dev);
+    HIP_TRY(hipGetLastError());
+    return dmc_set_prev_nw(d, nw + count);
+}
+
+extern "C" int qmc_dmc_truncate(qmc_dmc *d, int64_t new_nw)
+{
+    if (!d) return fail("qmc_dmc_truncate: null argument");
+    HIP_TRY(hipSetDevice(d->eng->device));
+    int64_t nw = 0;
+    int rc = qmc_dmc_num_walkers(d, &nw);
+    if (rc) return rc;
+    if (new_nw < 0 || new_nw > nw)
+        return fail("qmc_dmc_truncate: bad population size");
+    return dmc_set_prev_nw(d, new_nw);
+}

@@ -1,0 +1,239 @@
+"""Parity of the HIP engine (through the C-ABI) against the reference's golden
+vectors and against the CPU oracle on seeded inputs.  All tests need a GPU.
+
+Tolerances: the device code evaluates the same formulas with a different (but
+mathematically identical) arrangement -- angle-difference identities instead
+of a tan() per pair, N(N-1)/2 unordered pairs instead of N(N-1) ordered ones
+-- so deterministic quantities agree to rounding, not bit for bit:
+|delta| <= 2e-11 * max(1, |x|) for energies / drifts / log-psi.  Discrete
+quantities (move status, clone counts, cloning table, population size) must
+match exactly.
+"""
+import numpy as np
+import pytest
+
+from .conftest import oracle_model
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-11
+ALL_TAGS = ['box8', 'box16', 'box64', 'box128', 'box512', 'free16', 'deep100',
+            'deep16', 'ideal16', 'defect24', 'odd24']
+
+
+def close(a, b, rtol=RTOL):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b)))
+
+
+def worst(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def spec_from_golden(golden_params, tag):
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    return Spec(**golden_params[tag]['spec'])
+
+
+@pytest.fixture(scope='module')
+def engines(golden_params):
+    from phd_qmclib_amd.engine import ModelEngine
+    cache = {}
+
+    def get(tag):
+        if tag not in cache:
+            cache[tag] = ModelEngine(spec_from_golden(golden_params, tag).cfc_spec)
+        return cache[tag]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize('tag', ALL_TAGS)
+def test_evaluate_vs_reference_golden(engines, golden_kernels, tag):
+    """wf_abs_log / energy / ith_energy_and_drift on the fixed configurations
+    (random, regular, near-contact, wrap-edge) of every golden spec."""
+    eng = engines(tag)
+    out = eng.evaluate(golden_kernels[tag + '/pos'])
+    for name, got in [('wf_abs_log', out.wf_abs_log), ('energy', out.energy),
+                      ('ith_energy', out.ith_energy),
+                      ('ith_drift', out.drift)]:
+        ref = golden_kernels[tag + '/' + name]
+        assert close(got, ref), (tag, name, worst(got, ref))
+
+
+@pytest.mark.parametrize('tag,nconf', [('box16', 300), ('box64', 200),
+                                       ('box128', 64), ('box512', 6),
+                                       ('deep100', 40), ('defect24', 100),
+                                       ('odd24', 100), ('free16', 100)])
+def test_evaluate_vs_oracle_random(engines, oracle, golden_params, tag, nconf):
+    """Seeded random configurations (including negative / beyond-box positions
+    is NOT done here: sampling keeps walkers inside [0, L))."""
+    m = oracle_model(oracle, golden_params, tag)
+    rng = np.random.RandomState(hash(tag) % 2**31)
+    L, n = m.supercell_size, m.boson_number
+    pos = L * rng.random_sample((nconf, n))
+    wf, en, ith, dr = oracle.evaluate_set(m, pos)
+    out = engines(tag).evaluate(pos)
+    assert close(out.wf_abs_log, wf), worst(out.wf_abs_log, wf)
+    assert close(out.energy, en), worst(out.energy, en)
+    assert close(out.ith_energy, ith), worst(out.ith_energy, ith)
+    assert close(out.drift, dr), worst(out.drift, dr)
+
+
+def test_evaluate_ragged_batch(engines, oracle, golden_params):
+    """Batch sizes that do not fill a workgroup, and a batch of one."""
+    m = oracle_model(oracle, golden_params, 'box16')
+    rng = np.random.RandomState(5)
+    for W in (1, 3, 15, 17, 65):
+        pos = 16 * rng.random_sample((W, 16))
+        _, en, _, _ = oracle.evaluate_set(m, pos)
+        assert close(engines('box16').evaluate(pos).energy, en)
+
+
+@pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'deep16',
+                                 'defect24'])
+def test_vmc_tape_replay(engines, golden_vmc_tape, tag):
+    """Replay of the reference's recorded rand() stream: identical accept /
+    reject sequence, log-psi and energy series, block by block."""
+    from phd_qmclib_amd.engine import VmcEnsemble
+    g = golden_vmc_tape
+    eng = engines(tag)
+    n = eng.num_particles
+    nblocks, ns = g[tag + '/wf_abs_log'].shape
+    tape = g[tag + '/uniform'].reshape(1, -1, n + 1)
+    ens = VmcEnsemble(eng, 1, float(g[tag + '/move_spread']), rng_seed=7)
+    ens.set_state(g[tag + '/ini_pos'][None, :])
+    ens.set_tape(tape)
+    for b in range(nblocks):
+        out = ens.run_block(ns, series=True)
+        assert np.array_equal(out['move_stat'][:, 0], g[tag + '/move_stat'][b])
+        assert close(out['wf_abs_log'][:, 0], g[tag + '/wf_abs_log'][b])
+        assert close(out['energy'][:, 0], g[tag + '/energy'][b])
+        assert out['num_accepted'][0] / ns == g[tag + '/accept_rate'][b]
+        assert close(out['sum_energy'][0], g[tag + '/energy'][b].sum(),
+                     rtol=1e-12 * ns)
+    pos, wf, _ = ens.get_state()
+    assert close(pos[0], g[tag + '/last_pos'], rtol=1e-13)
+    ens.close()
+
+
+@pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'cap8'])
+def test_dmc_tape_replay(engines, golden_dmc_tape, tag):
+    """Replay of the reference's rand()/normal() streams through the device
+    branching scan + propagation: population sizes and cloning tables exact,
+    estimators and yielded walkers to rounding (includes the run that is
+    truncated at max_num_walkers)."""
+    from phd_qmclib_amd.engine import DmcEnsemble
+    g = golden_dmc_tape
+    stag = 'box8' if tag == 'cap8' else tag
+    eng = engines(stag)
+    n = eng.num_particles
+    dt, target, maxw, kappa, steps, n_ini = g[tag + '/cfg']
+    target, maxw, steps, n_ini = int(target), int(maxw), int(steps), int(n_ini)
+    ens = DmcEnsemble(eng, dt, maxw, target, kappa, rng_seed=11)
+    # build_state keeps the last `target` configurations (mrbp_qmc/dmc.py:290)
+    ens.set_state(g[tag + '/ini_pos'][-target:])
+    n_ini = min(n_ini, target)
+    st0 = ens.get_state()
+    assert st0.num_walkers == n_ini
+    assert close(st0.energy[:n_ini], g[tag + '/ini_energy'][:n_ini])
+    assert close(st0.confs[:n_ini, 1], g[tag + '/ini_drift'][:n_ini])
+    assert close(st0.ref_energy, float(g[tag + '/ini_ref_energy']))
+    nu, nn = g[tag + '/n_uniform'], g[tag + '/n_normal']
+    u_off = np.concatenate([[0], np.cumsum(nu)[:-1]])
+    g_off = np.concatenate([[0], np.cumsum(nn)[:-1]])
+    ens.set_tape(g[tag + '/uniform'], g[tag + '/normal'], u_off, g_off)
+    for t in range(steps):
+        ser = ens.run_block(1)
+        nw = int(g[tag + '/num_walkers'][t])
+        assert int(ser.num_walkers[0]) == nw, t
+        st = ens.get_state()
+        assert st.num_walkers == nw
+        assert np.array_equal(st.cloning_ref[:nw],
+                              g[tag + '/cloning_ref'][t, :nw]), t
+        assert close(ser.energy[0], g[tag + '/energy'][t]), t
+        assert ser.weight[0] == g[tag + '/weight'][t]
+        assert close(ser.ref_energy[0], g[tag + '/ref_energy'][t]), t
+        assert close(ser.accum_energy[0], g[tag + '/accum_energy'][t]), t
+        assert close(st.confs[:nw], g[tag + '/confs'][t, :nw], rtol=1e-10), t
+        assert close(st.energy[:nw], g[tag + '/walker_energy'][t, :nw]), t
+        assert not st.mask[:nw].any() and st.mask[nw:].all()
+    ens.close()
+
+
+def test_dmc_tape_replay_one_block(engines, golden_dmc_tape):
+    """The same replay enqueued as ONE block call (no host sync between time
+    steps) gives the same series as step-by-step."""
+    from phd_qmclib_amd.engine import DmcEnsemble
+    g, tag = golden_dmc_tape, 'box8'
+    eng = engines('box8')
+    dt, target, maxw, kappa, steps, n_ini = g[tag + '/cfg']
+    ens = DmcEnsemble(eng, dt, int(maxw), int(target), kappa, rng_seed=11)
+    ens.set_state(g[tag + '/ini_pos'])
+    nu, nn = g[tag + '/n_uniform'], g[tag + '/n_normal']
+    ens.set_tape(g[tag + '/uniform'], g[tag + '/normal'],
+                 np.concatenate([[0], np.cumsum(nu)[:-1]]),
+                 np.concatenate([[0], np.cumsum(nn)[:-1]]))
+    ser = ens.run_block(int(steps))
+    assert np.array_equal(ser.num_walkers.astype(np.int64),
+                          g[tag + '/num_walkers'])
+    assert close(ser.energy, g[tag + '/energy'])
+    assert close(ser.ref_energy, g[tag + '/ref_energy'])
+    assert close(ser.accum_energy, g[tag + '/accum_energy'])
+    ens.close()
+
+
+def test_vmc_philox_matches_oracle(engines, oracle, golden_params):
+    """Same seed, same counter RNG: device chains and oracle chains follow the
+    same trajectories (Philox4x32-10 keyed by (seed; chain, step, particle,
+    stream) on both sides)."""
+    from phd_qmclib_amd.engine import VmcEnsemble
+    tag, W, ns = 'box16', 37, 24
+    m = oracle_model(oracle, golden_params, tag)
+    rng = np.random.RandomState(17)
+    pos0 = 16 * rng.random_sample((W, 16))
+    ens = VmcEnsemble(engines(tag), W, 0.125, rng_seed=123456789)
+    ens.set_state(pos0)
+    out = ens.run_block(ns, series=True)
+    out2 = ens.run_block(ns, series=True)
+    n_match = 0
+    for c in range(W):
+        ch = oracle.VmcChain(m, pos0[c], 0.125, seed=123456789, chain=c)
+        wf, en, st, _ = ch.run(ns)
+        wf2, en2, st2, _ = ch.run(ns)
+        ok = (np.array_equal(st, out['move_stat'][:, c]) and
+              np.array_equal(st2, out2['move_stat'][:, c]))
+        if ok:
+            n_match += 1
+            assert close(np.r_[en, en2], np.r_[out['energy'][:, c],
+                                               out2['energy'][:, c]], 1e-9)
+            assert close(np.r_[wf, wf2], np.r_[out['wf_abs_log'][:, c],
+                                               out2['wf_abs_log'][:, c]], 1e-9)
+    # a rounding-level difference may flip a marginal accept; nearly all match
+    assert n_match >= W - 1
+    ens.close()
+
+
+def test_dmc_philox_matches_oracle(engines, oracle, golden_params):
+    from phd_qmclib_amd.engine import DmcEnsemble
+    tag = 'box16'
+    m = oracle_model(oracle, golden_params, tag)
+    rng = np.random.RandomState(23)
+    pos0 = 16 * rng.random_sample((200, 16))
+    cfg = dict(time_step=1e-3, max_num_walkers=256, target_num_walkers=200)
+    ens = DmcEnsemble(engines(tag), num_walkers_control_factor=0.5,
+                      rng_seed=424242, **cfg)
+    ens.set_state(pos0)
+    orc = oracle.DmcEnsemble(m, pos0, 1e-3, 256, 200, 0.5, seed=424242)
+    ser = ens.run_block(12)
+    for t in range(12):
+        o = orc.step()
+        assert int(ser.num_walkers[t]) == o.num_walkers, t
+        assert close(ser.energy[t], o.energy, 1e-9), t
+        assert close(ser.ref_energy[t], o.ref_energy, 1e-9), t
+    st = ens.get_state()
+    assert np.array_equal(st.cloning_ref[:st.num_walkers],
+                          orc.cloning_ref[:st.num_walkers])
+    ens.close()
