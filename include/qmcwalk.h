@@ -125,11 +125,12 @@ int qmc_vmc_get_state(qmc_vmc *v, double *pos, double *wf_abs_log,
 /* One block of `nyield` generator yields per chain.  Per-chain block sums
  * (sum of energy, of energy^2, accepted count) are always produced on the
  * device; the host copies requested here synchronise.  Series buffers are
- * [nyield][W] (step-major) host arrays or NULL. */
+ * [nyield][W] (step-major) host arrays or NULL; series_pos is [nyield][W][N]
+ * (the chain configurations `as_chain` returns, qmc_base/vmc.py:785-900). */
 int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_energy,
                       double *sum_energy2, int64_t *num_accepted,
                       double *series_wf, double *series_energy,
-                      uint8_t *series_stat);
+                      uint8_t *series_stat, double *series_pos);
 /* Device addresses of the per-chain block sums of the last block
  * (sum_e[W], sum_e2[W], n_acc[W]) for on-device reductions / collectives. */
 int qmc_vmc_block_sums_dev(qmc_vmc *v, double **sum_e, double **sum_e2,
@@ -149,10 +150,11 @@ void qmc_dmc_destroy(qmc_dmc *d);
 int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
                       int use_ref_energy, double ref_energy);
 /* Restart from a yielded State (qmc_base/dmc.py:707-716): confs[nw][2][N],
- * energy[nw], weight[nw] copied as they are. */
+ * energy[nw], weight[nw] copied as they are; slot_energy[maxw] (or NULL) is the
+ * whole props.energy array of that State. */
 int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw, const double *confs,
                            const double *energy, const double *weight,
-                           double ref_energy);
+                           const double *slot_energy, double ref_energy);
 /* `nsteps` generator iterations (branch -> diffuse/evaluate -> estimators ->
  * E_ref feedback).  Per-step series are host arrays of length nsteps or NULL
  * (PropsData, qmc_base/dmc.py:130-143). */

@@ -326,7 +326,7 @@ def gen_stats():
     # VMC: per seed 16 blocks x 512 steps, first 2 burned
     ns, nb, burn = 512, 16, 2
     vm = []
-    for seed in (1, 2, 3, 4):
+    for seed in range(1, 25):
         np.random.seed(1000 + seed)
         ini = spec.init_get_sys_conf()
         smp = mrbp_qmc.vmc.Sampling(spec, move_spread=0.125, rng_seed=seed)
@@ -345,7 +345,7 @@ def gen_stats():
     # DMC: per seed target 96 / max 128, 10 blocks x 32 steps, first 2 burned
     dt, target, maxw, kappa, nts, nbd, burnd = 1e-3, 96, 128, 0.5, 32, 10, 2
     dm = []
-    for seed in (1, 2, 3):
+    for seed in range(1, 11):
         np.random.seed(2000 + seed)
         ini = spec.init_get_sys_conf()
         vs = mrbp_qmc.vmc.Sampling(spec, move_spread=0.125, rng_seed=seed)

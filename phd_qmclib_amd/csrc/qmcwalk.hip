@@ -154,6 +154,7 @@ struct VmcArgs {
     long long *n_acc;
     double *ser_wf, *ser_e;   // [nyield][W] or null
     unsigned char *ser_stat;
+    double *ser_pos;          // [nyield][W][N] or null
     const double *tape;   // [W][tape_steps][N+1] or null
     long long tape_steps;
     long long W;
@@ -249,6 +250,13 @@ vmc_block_kernel(DevModel m, VmcArgs a)
             if (a.ser_wf) a.ser_wf[y * a.W + w] = wf_cur;
             if (a.ser_e) a.ser_e[y * a.W + w] = e_cur;
             if (a.ser_stat) a.ser_stat[y * a.W + w] = acc ? 1 : 0;
+        }
+        if (active && a.ser_pos) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                int i = gl + G * p;
+                if (i < n) a.ser_pos[(y * a.W + w) * n + i] = z[p];
+            }
         }
         if (!forced) { ++step; ++treal; }
     }
@@ -970,7 +978,7 @@ extern "C" int qmc_vmc_block_sums_dev(qmc_vmc *v, double **se, double **se2,
 extern "C" int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_e,
                                  double *sum_e2, int64_t *n_acc,
                                  double *ser_wf, double *ser_e,
-                                 uint8_t *ser_stat)
+                                 uint8_t *ser_stat, double *ser_pos)
 {
     if (!v) return fail("qmc_vmc_run_block: null argument");
     if (nyield <= 0) return fail("qmc_vmc_run_block: nyield must be >= 1");
@@ -982,13 +990,15 @@ extern "C" int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_e,
         return fail("qmc_vmc_run_block: tape exhausted");
     double *dwf = nullptr, *de = nullptr;
     unsigned char *dst = nullptr;
+    double *dpos = nullptr;
+    if (ser_pos && dev_alloc(&dpos, ny * W * (size_t)e->dm.n)) return 1;
     if (ser_wf && dev_alloc(&dwf, ny * W)) return 1;
     if (ser_e && dev_alloc(&de, ny * W)) return 1;
     if (ser_stat && dev_alloc(&dst, ny * W)) return 1;
     VmcArgs a;
     a.pos = v->pos; a.wf = v->wf; a.ecarry = v->ecarry;
     a.sum_e = v->sum_e; a.sum_e2 = v->sum_e2; a.n_acc = v->n_acc;
-    a.ser_wf = dwf; a.ser_e = de; a.ser_stat = dst;
+    a.ser_wf = dwf; a.ser_e = de; a.ser_stat = dst; a.ser_pos = dpos;
     a.tape = v->tape ? v->tape + (size_t)v->tape_used * (e->dm.n + 1) : nullptr;
     a.tape_steps = v->tape_steps;
     a.W = v->W; a.nyield = nyield;
@@ -1014,7 +1024,11 @@ extern "C" int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_e,
                  hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
     if (ser_stat) { HIP_TRY(hipMemcpyAsync(ser_stat, dst, ny * W,
                     hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
+    if (ser_pos) { HIP_TRY(hipMemcpyAsync(ser_pos, dpos,
+                   ny * W * (size_t)e->dm.n * sizeof(double),
+                   hipMemcpyDeviceToHost, e->stream)); need_sync = true; }
     if (need_sync) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (dpos) hipFree(dpos);
     if (dwf) hipFree(dwf);
     if (de) hipFree(de);
     if (dst) hipFree(dst);
@@ -1171,7 +1185,9 @@ extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
 extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
                                       const double *confs,
                                       const double *energy,
-                                      const double *weight, double ref_energy)
+                                      const double *weight,
+                                      const double *slot_energy,
+                                      double ref_energy)
 {
     if (!d || !confs || !energy || !weight)
         return fail("qmc_dmc_set_full_state: null argument");
@@ -1200,8 +1216,14 @@ extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
                            hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d->weight[0], weight, (size_t)nw * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d->eslot, energy, (size_t)nw * sizeof(double),
-                           hipMemcpyHostToDevice, e->stream));
+    // the reference copies the whole props.energy array of the initial state
+    // into its `actual` buffer (qmc_base/dmc.py:707-708), stale tail included
+    if (slot_energy)
+        HIP_TRY(hipMemcpyAsync(d->eslot, slot_energy, W * sizeof(double),
+                               hipMemcpyHostToDevice, e->stream));
+    else
+        HIP_TRY(hipMemcpyAsync(d->eslot, energy, (size_t)nw * sizeof(double),
+                               hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return dmc_reset_ctl(d, nw, ref_energy);
 }
@@ -1314,6 +1336,8 @@ extern "C" int qmc_dmc_read_series(qmc_dmc *d, int64_t nsteps, double *energy,
     if (accum_energy) HIP_TRY(hipMemcpyAsync(accum_energy, d->ser_acc, ns * 8,
                                              hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    // a full read consumes the series (split-step drivers append to it)
+    if (nsteps == d->ser_len) d->ser_len = 0;
     return 0;
 }
 

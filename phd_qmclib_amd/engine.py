@@ -165,13 +165,17 @@ class VmcEnsemble:
             and tape.shape[2] == self.num_particles + 1
         check(self._lib.qmc_vmc_set_tape(self._h, ptr(tape), tape.shape[1]))
 
-    def run_block(self, nyield: int, sums: bool = True, series: bool = False):
+    def run_block(self, nyield: int, sums: bool = True, series: bool = False,
+                  confs: bool = False):
         """Advance every chain by `nyield` generator yields.
         -> dict with sum_energy, sum_energy2, num_accepted ([W]) and, if
-        `series`, wf_abs_log / energy / move_stat ([nyield, W])."""
+        `series`, wf_abs_log / energy / move_stat ([nyield, W]); if `confs`,
+        pos ([nyield, W, N])."""
         W = self.num_chains
         out = {}
-        se = se2 = na = swf = sen = sst = None
+        se = se2 = na = swf = sen = sst = spos = None
+        if confs:
+            spos = np.zeros((nyield, W, self.num_particles))
         if sums:
             se, se2 = np.zeros(W), np.zeros(W)
             na = np.zeros(W, dtype=np.int64)
@@ -180,7 +184,10 @@ class VmcEnsemble:
             sst = np.zeros((nyield, W), dtype=np.uint8)
         check(self._lib.qmc_vmc_run_block(self._h, int(nyield), ptr(se),
                                           ptr(se2), ptr(na, _i64p), ptr(swf),
-                                          ptr(sen), ptr(sst, _u8p)))
+                                          ptr(sen), ptr(sst, _u8p),
+                                          ptr(spos)))
+        if confs:
+            out.update(pos=spos)
         if sums:
             out.update(sum_energy=se, sum_energy2=se2, num_accepted=na)
         if series:
@@ -257,15 +264,20 @@ class DmcEnsemble:
             self._h, pos.shape[0], ptr(pos), int(ref_energy is not None),
             float(ref_energy if ref_energy is not None else 0.0)))
 
-    def set_full_state(self, confs, energy, weight, ref_energy: float):
+    def set_full_state(self, confs, energy, weight, ref_energy: float,
+                       slot_energy=None):
         confs = np.ascontiguousarray(confs, dtype=np.float64)
         energy = np.ascontiguousarray(energy, dtype=np.float64)
         weight = np.ascontiguousarray(weight, dtype=np.float64)
         nw = confs.shape[0]
         assert confs.shape == (nw, 2, self.num_particles)
         assert energy.shape == (nw,) and weight.shape == (nw,)
+        if slot_energy is not None:
+            slot_energy = np.ascontiguousarray(slot_energy, dtype=np.float64)
+            assert slot_energy.shape == (self.max_num_walkers,)
         check(self._lib.qmc_dmc_set_full_state(self._h, nw, ptr(confs),
                                                ptr(energy), ptr(weight),
+                                               ptr(slot_energy),
                                                float(ref_energy)))
 
     def set_tape(self, u, g, u_off, g_off):

@@ -3,3 +3,5 @@ from .model import (  # noqa: F401
     CFCSpec, OBFParams, Params, Spec, TBFParams, core_funcs,
     DIST_RAND, DIST_REGULAR, SysConfSlot
 )
+from . import dmc, vmc  # noqa: F401,E402
+from . import dmc_exec, vmc_exec  # noqa: F401,E402

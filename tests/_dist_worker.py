@@ -1,0 +1,138 @@
+"""Worker processes of the world_size-2 gloo tests (CPU).  The population
+handle is an ORACLE-backed stand-in with the method set of
+`engine.DmcEnsemble` -- test infrastructure, never the product path."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class OracleShard:
+    """engine.DmcEnsemble look-alike over oracle/qmc_oracle.c."""
+
+    def __init__(self, orc, model, pos, dt, local_max, global_target, kappa,
+                 seed, slot0):
+        self.orc = orc
+        self.n = model.boson_number
+        self.maxw = local_max
+        self.ens = orc.DmcEnsemble(model, pos, dt, local_max, global_target,
+                                   kappa, seed=seed, slot0=slot0)
+        # build_state used the local mean as E_ref; keep it
+        self.dt, self.kappa, self.target = dt, kappa, float(global_target)
+        self.series = []
+        self._saved = None
+
+    def _view(self, ptr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(
+            C.cast(ptr, C.POINTER(C.c_double)), shape=(n,)).reshape(shape)
+
+    def step_local(self, partial_ptr):
+        st = self.ens.st
+        self._saved = (st.total_energy, st.total_weight)
+        out = self.ens.step()
+        self._last = out
+        buf = (C.c_double * 2).from_address(partial_ptr)
+        buf[0], buf[1] = out.energy, float(out.num_walkers)
+
+    def step_finish(self, total_ptr):
+        from math import log
+        buf = (C.c_double * 2).from_address(total_ptr)
+        e_t, w_t = buf[0], buf[1]
+        st = self.ens.st
+        st.total_energy = self._saved[0] + e_t
+        st.total_weight = self._saved[1] + w_t
+        accum = st.total_energy / st.total_weight
+        st.ref_energy = accum - self.kappa * log(w_t / self.target) / self.dt
+        self.series.append((e_t, w_t, self._last.num_walkers, st.ref_energy,
+                            accum))
+
+    def read_series(self, nsteps):
+        rows = self.series[:nsteps]
+        self.series = self.series[nsteps:]
+        return np.array(rows)
+
+    def num_walkers(self):
+        return int(self.ens.st.prev_num_walkers)
+
+    def _pop(self):
+        st = self.ens.st
+        return (self._view(st.prev_confs, (self.maxw, 2, self.n)),
+                self._view(st.prev_energy, (self.maxw,)),
+                self._view(st.prev_weight, (self.maxw,)))
+
+    def export_walkers(self, first, count, buf_ptr):
+        confs, en, wt = self._pop()
+        rec = 2 * self.n + 2
+        out = self._view(buf_ptr, (count, rec))
+        out[:, :self.n] = confs[first:first + count, 0]
+        out[:, self.n:2 * self.n] = confs[first:first + count, 1]
+        out[:, 2 * self.n] = en[first:first + count]
+        out[:, 2 * self.n + 1] = wt[first:first + count]
+
+    def import_walkers(self, count, buf_ptr):
+        confs, en, wt = self._pop()
+        rec = 2 * self.n + 2
+        src = self._view(buf_ptr, (count, rec))
+        nw = self.num_walkers()
+        assert nw + count <= self.maxw
+        confs[nw:nw + count, 0] = src[:, :self.n]
+        confs[nw:nw + count, 1] = src[:, self.n:2 * self.n]
+        en[nw:nw + count] = src[:, 2 * self.n]
+        wt[nw:nw + count] = src[:, 2 * self.n + 1]
+        self.ens.st.prev_num_walkers = nw + count
+
+    def truncate(self, new_nw):
+        assert 0 <= new_nw <= self.num_walkers()
+        self.ens.st.prev_num_walkers = new_nw
+
+    def fingerprint(self):
+        confs, en, wt = self._pop()
+        nw = self.num_walkers()
+        return sorted(float(x) for x in en[:nw])
+
+
+def main():
+    rank, world, port, out_dir = (int(sys.argv[1]), int(sys.argv[2]),
+                                  sys.argv[3], sys.argv[4])
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                      RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import qmc_oracle as orc
+    from phd_qmclib_amd.dist import DistributedDmc
+    params = json.load(open(os.path.join(ROOT, 'tests', 'golden',
+                                         'params.json')))['box8']
+    m = orc.model_from_params(params['params'], params['obf_params'],
+                              params['tbf_params'])
+    n = m.boson_number
+    rng = np.random.RandomState(100 + rank)
+    # deliberately unbalanced start: rank 0 gets 3x the walkers of rank 1
+    n0 = 36 if rank == 0 else 12
+    pos = n * rng.random_sample((n0, n))
+    shard = OracleShard(orc, m, pos, 1e-3, 64, 48, 0.5, seed=9,
+                        slot0=rank * 64)
+    dd = DistributedDmc(shard, n, 'cpu', rebalance_every=4,
+                        imbalance_tol=0.0)
+    res = dict(rank=rank)
+    before = dd.global_counts()
+    fp_before = shard.fingerprint()
+    moved = dd.rebalance(force=True)
+    after = dd.global_counts()
+    res.update(counts_before=before, counts_after=after, moved=moved,
+               fp_before=fp_before, fp_after=shard.fingerprint())
+    ser = dd.run_block(10)
+    res.update(series=ser.tolist(), counts_end=dd.global_counts(),
+               walkers_moved=dd.walkers_moved)
+    with open(os.path.join(out_dir, f'rank{rank}.json'), 'w') as fp:
+        json.dump(res, fp)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
