@@ -100,13 +100,25 @@ void orc_philox_uniform2(uint64_t seed, uint32_t slot, uint32_t step,
     u[1] = u53(c[2], c[3]);
 }
 
+void orc_philox_normal2(uint64_t seed, uint32_t slot, uint32_t step,
+                        uint32_t index, uint32_t stream, double *g)
+{
+    /* Box-Muller pair; 1-u keeps the log argument in (0, 1] */
+    double u[2];
+    orc_philox_uniform2(seed, slot, step, index, stream, u);
+    double r = sqrt(-2.0 * log(1.0 - u[0]));
+    g[0] = r * cos(6.283185307179586476925 * u[1]);
+    g[1] = r * sin(6.283185307179586476925 * u[1]);
+}
+
 double orc_philox_normal(uint64_t seed, uint32_t slot, uint32_t step,
                          uint32_t index, uint32_t stream)
 {
-    /* Box-Muller, cosine branch; 1-u keeps the log argument in (0, 1] */
-    double u[2];
-    orc_philox_uniform2(seed, slot, step, index, stream, u);
-    return sqrt(-2.0 * log(1.0 - u[0])) * cos(6.283185307179586476925 * u[1]);
+    /* DMC diffusion keying: time steps 2m and 2m+1 share one Philox block,
+     * cosine branch on even steps, sine branch on odd ones */
+    double g[2];
+    orc_philox_normal2(seed, slot, step >> 1, index, stream, g);
+    return g[step & 1u];
 }
 
 /* ------------------------------------------------------------------ */
@@ -336,20 +348,24 @@ int64_t orc_vmc_chain(const orc_model *m, const orc_vmc_cfg *cfg,
             stat = 1;
         } else {
             /* qmc_base/jastrow/vmc.py:208-224 + mrbp_qmc/vmc.py:215-233 */
+            double ua_spare = 1.0;
             for (int64_t i = 0; i < nop; ++i) {
                 double d;
                 if (tape) {
                     d = cfg->gaussian ? 0 + cfg->move_spread * (*tape++)
                                       : ((*tape++) - 0.5) * cfg->move_spread;
                 } else if (cfg->gaussian) {
-                    d = 0 + cfg->move_spread *
-                        orc_philox_normal(cfg->seed, cfg->chain, step,
-                                          (uint32_t)i, ORC_STREAM_VMC_MOVE);
+                    double g[2];
+                    orc_philox_normal2(cfg->seed, cfg->chain, step,
+                                       (uint32_t)i, ORC_STREAM_VMC_MOVE, g);
+                    d = 0 + cfg->move_spread * g[0];
                 } else {
                     double u[2];
                     orc_philox_uniform2(cfg->seed, cfg->chain, step,
                                         (uint32_t)i, ORC_STREAM_VMC_MOVE, u);
                     d = (u[0] - 0.5) * cfg->move_spread;
+                    /* the accept draw is the spare double of particle 0 */
+                    if (i == 0) ua_spare = u[1];
                 }
                 prop[i] = recast(pos[i] + d, 0., 1. * L);
             }
@@ -357,11 +373,13 @@ int64_t orc_vmc_chain(const orc_model *m, const orc_vmc_cfg *cfg,
             double ua;
             if (tape) {
                 ua = *tape++;
-            } else {
+            } else if (cfg->gaussian) {
                 double u[2];
                 orc_philox_uniform2(cfg->seed, cfg->chain, step, 0,
                                     ORC_STREAM_VMC_ACCEPT, u);
                 ua = u[0];
+            } else {
+                ua = ua_spare;
             }
             stat = 0;
             /* qmc_base/vmc.py:636 */

@@ -48,6 +48,9 @@ enum { ORC_STREAM_VMC_MOVE = 0, ORC_STREAM_VMC_ACCEPT = 1,
        ORC_STREAM_DMC_BRANCH = 2, ORC_STREAM_DMC_DIFFUSE = 3 };
 void orc_philox_uniform2(uint64_t seed, uint32_t slot, uint32_t step,
                          uint32_t index, uint32_t stream, double *u);
+void orc_philox_normal2(uint64_t seed, uint32_t slot, uint32_t step,
+                        uint32_t index, uint32_t stream, double *g);
+/* DMC diffusion normal: steps 2m / 2m+1 share one block (cos / sin branch) */
 double orc_philox_normal(uint64_t seed, uint32_t slot, uint32_t step,
                          uint32_t index, uint32_t stream);
 

@@ -12,17 +12,26 @@
 //
 // Pair arithmetic: no transcendental per pair.  With a_i = pi z_i / L and
 // b_i = k2 z_i tabulated per particle (sin, cos), the angle-difference
-// identities give sin/cos of a_i-a_j and b_i-b_j with 4 FMA-class ops each;
-//   long range  (r >= rm): f2'/f2 sgn = (pi/L) beta cot(a_i-a_j)       (period L:
-//                          the minimum image needs no explicit wrap)
-//   short range (r <  rm): f2'/f2     = -k2 tan(k2 r - k2 r_off)
-// both reduce to ONE division q = X/Y per pair, and
-//   -f2''/f2 + (f2'/f2)^2 = c_B (1 + q^2),  c_B = k2^2 or (pi/L)^2 beta.
-// (reference formulas: mrbp_qmc/model.py:468-529).
+// identities give sin/cos of a_i-a_j and b_i-b_j with 2 FMA-class ops each.
+// Both branches of the two-body factor (mrbp_qmc/model.py:468-529) reduce to
+// ONE division q = X / Y per pair with the drift coefficient folded into X:
+//   long  (r >= rm): X = (pi/L) beta cos(a_i-a_j), Y = sin(a_i-a_j)
+//                    (period L: the minimum image needs no explicit wrap)
+//   short (r <  rm): X = -k2 sin(k2 d -+ phi),      Y = cos(k2 r - phi)
+// so that q is the pair's contribution to the drift of particle i, and
+//   -f2''/f2 + (f2'/f2)^2 = k2^2 + q^2                   (short)
+//                         = (pi/L)^2 beta + q^2 / beta   (long).
+// The short branch runs under an exec mask (a real divergent branch, no
+// selects).
+//
+// On gfx950 every VALU instruction costs ~4 cycles per wave64 and this path is
+// VALU-bound (profiles/): instruction count is the whole game here.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "qmc_math.h"
 
 #define QMC_PI 3.141592653589793238462643383279502884
 
@@ -32,34 +41,39 @@ struct DevModel {
     int defects_sep;
     int zclass;            // classify pairs from positions (rm close to L/2)
     double L, half_L, rm, L_minus_rm;
-    double pi_L;           // pi / L
+    double two_over_L;     // 2 / L            (angle pi z / L = (pi/2) * u)
+    double k2_2pi;         // k2 * 2 / pi      (angle k2 z     = (pi/2) * u)
     double k2, k2sq;
+    double m_k2cphi;       // -k2 cos(k2 r_off)
+    double k2sphi;         //  k2 sin(k2 r_off)
     double cphi, sphi;     // cos/sin(k2 r_off)
     double cth, sth;       // cos/sin(k2 L)
     double sin_rm;         // sin(pi rm / L)
     double a_long, b_long; // (pi/L) beta, (pi/L)^2 beta
+    double inv_beta;       // 1 / beta
     double beta, log_am;
     // one-body (Kronig-Penney)
     double z_a, z_b, k1, kp1, e0, v0, v0d, v0_minus_e0, cf;
+    double k1_2pi;         // k1 * 2 / pi
 };
 
 // ---------------------------------------------------------------- RNG ----
 // Philox4x32-10 (Salmon et al. 2011), counter = (slot, step, index, stream),
-// key = seed.  Same algorithm as the oracle so seeded runs line up.
+// key = seed.  Same algorithm and keying as the oracle so seeded runs line up.
 enum { STREAM_VMC_MOVE = 0, STREAM_VMC_ACCEPT = 1, STREAM_DMC_BRANCH = 2,
        STREAM_DMC_DIFFUSE = 3 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0,
                                               uint32_t k1)
 {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(M0, c[0]), l0 = M0 * c[0];
-        uint32_t h1 = __umulhi(M1, c[2]), l1 = M1 * c[2];
-        uint32_t n0 = h1 ^ c[1] ^ k0;
-        uint32_t n2 = h0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = l1; c[2] = n2; c[3] = l0;
+        // one 32x32->64 multiply each (v_mad_u64_u32)
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
@@ -81,13 +95,20 @@ __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint32_t slot,
     u1 = u53(c[2], c[3]);
 }
 
-__device__ __forceinline__ double philox_normal(uint64_t seed, uint32_t slot,
-                                                uint32_t step, uint32_t index,
-                                                uint32_t stream)
+// Box-Muller pair from one Philox block: both standard normals.
+__device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t slot,
+                                               uint32_t step, uint32_t index,
+                                               uint32_t stream, double &g0,
+                                               double &g1)
 {
     double u0, u1;
     philox_uniform2(seed, slot, step, index, stream, u0, u1);
-    return sqrt(-2.0 * log(1.0 - u0)) * cos(6.283185307179586476925 * u1);
+    // 1 - u0 is in (0, 1]: log <= 0
+    double r = fast_sqrt(fmax(-2.0 * log_pos(1.0 - u0), 1e-300));
+    double s, c;
+    sincos_halfpi(4.0 * u1, s, c);          // angle 2 pi u1
+    g0 = r * c;
+    g1 = r * s;
 }
 
 // ------------------------------------------------------------ helpers ----
@@ -112,20 +133,6 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
-template <int G>
-__device__ __forceinline__ int group_sum_int(int v)
-{
-#pragma unroll
-    for (int m = 1; m < G; m <<= 1)
-        v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-__device__ __forceinline__ double flip_sign_if(double x, bool neg)
-{
-    return neg ? -x : x;
-}
-
 // Per-particle table entry kept in registers by the owner and published to LDS.
 struct PTab {
     double s, c;    // sin/cos(pi z / L)
@@ -133,90 +140,86 @@ struct PTab {
 };
 
 // One-body factor (mrbp_qmc/model.py:404-464) and lattice potential (:533-551).
-// ldz  = f1'/f1; kin = -f1''/f1 + ldz^2 + V(z); f1 > 0 is the factor itself.
+// ldz = f1'/f1; kin_pot = -f1''/f1 + ldz^2 + V(z); f1 > 0 is the factor itself.
 __device__ __forceinline__ void one_body(const DevModel &m, double z,
                                          double &ldz, double &kin_pot,
                                          double &f1)
 {
     double n_cell = floor(z);
     double z_cell = z - n_cell;
-    bool barrier = m.z_a < z_cell;
-    if (barrier) {
+    if (m.z_a < z_cell) {
+        // barrier: cosh / tanh through one exponential
         double x = m.kp1 * (z_cell - 1.0 + 0.5 * m.z_b);
-        double t = tanh(x);
-        ldz = m.kp1 * t;
-        f1 = cosh(x);
-        long long nc = (long long)n_cell;
-        long long r = nc % m.defects_sep;
+        double e = exp_bounded(x);
+        double ei = fast_rcp(e);
+        double ch2 = e + ei;                    // 2 cosh
+        ldz = m.kp1 * fast_div(e - ei, ch2);
+        f1 = 0.5 * ch2;
+        int nc = (int)n_cell;
+        int r = nc % m.defects_sep;
         if (r < 0) r += m.defects_sep;
         double v = (r == 0) ? m.v0d : m.v0;
-        kin_pot = -m.v0_minus_e0 + ldz * ldz + v;
+        kin_pot = fma(ldz, ldz, v - m.v0_minus_e0);
     } else {
-        double x = m.k1 * (z_cell - 0.5 * m.z_a);
         double sx, cx;
-        sincos(x, &sx, &cx);
-        ldz = -m.k1 * (sx / cx);
+        sincos_halfpi(m.k1_2pi * (z_cell - 0.5 * m.z_a), sx, cx);
+        ldz = -m.k1 * fast_div(sx, cx);
         f1 = m.cf * cx;
-        kin_pot = m.e0 + ldz * ldz;
+        kin_pot = fma(ldz, ldz, m.e0);
     }
 }
 
-// Result of one pair evaluation, as seen from the "own" particle i.
-//   w   : contribution to drift_i (partner j gets -w)
-//   q   : the ratio X/Y;   isshort : r < rm
-//   fac : |f2| up to the constant am (short: cos(k2 r - phi), long: |sin|)
-struct PairOut {
-    double w, q, fac;
-    bool isshort;
-};
-
+// One pair, seen from the own particle (table `a`, long-range numerator
+// coefficients aks/akc = a_long * (sin, cos)) against partner table `b`.
+//   q       : contribution to the drift of the own particle (partner: -q)
+//   Yout    : the denominator = the factor |f2| up to constants
+//             (short: cos(k2 r - phi); long: sin(pi d / L), signed)
+//   isshort : r < rm
 template <bool ZCLASS>
-__device__ __forceinline__ PairOut pair_eval(const DevModel &m, const PTab &a,
-                                             double za, const PTab &b,
-                                             double zb)
+__device__ __forceinline__ void pair_core(const DevModel &m, const PTab &a,
+                                          double aks, double akc, double za,
+                                          const PTab &b, double zb, double &q,
+                                          double &Yout, bool &isshort)
 {
-    PairOut o;
     double S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
-    double C = a.c * b.c + a.s * b.s;     // cos
-    double Su = a.su * b.cu - a.cu * b.su; // sin(k2 (z_a - z_b))
-    double Cu = a.cu * b.cu + a.su * b.su;
-    bool neg, wrapped, isshort;
+    double X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    double Y = S;
+    bool wrapped;
     if (ZCLASS) {
-        double D = za - zb;
-        double aD = fabs(D);
-        neg = D < 0.0;
+        double aD = fabs(za - zb);
         wrapped = aD > m.half_L;
         isshort = (aD < m.rm) | (aD > m.L_minus_rm);
     } else {
-        neg = S < 0.0;                    // sign(z_a - z_b)
-        wrapped = C < 0.0;                // |z_a - z_b| > L/2
+        wrapped = X < 0.0;                // |z_a - z_b| > L/2
         isshort = fabs(S) < m.sin_rm;     // min-image r < rm
     }
-    // sin/cos of k2 * r for the min-image distance r (valid when short)
-    double Pq = flip_sign_if(Su, neg);    // sin(k2 |D|)
-    double Aw = m.sth * Cu - m.cth * Pq;  // sin(k2 (L - |D|))
-    double Bw = m.cth * Cu + m.sth * Pq;
-    double A = wrapped ? Aw : Pq;
-    double B = wrapped ? Bw : Cu;
-    double Xs = A * m.cphi - B * m.sphi;  // sin(k2 r - phi)
-    double Ys = B * m.cphi + A * m.sphi;  // cos(k2 r - phi)
-    double X = isshort ? Xs : C;
-    double Y = isshort ? Ys : S;
-    double q = X / Y;
-    // sign of the min-image separation d: flips when the pair wraps
-    bool dneg = neg != wrapped;
-    double cs = flip_sign_if(m.k2, !dneg); // -k2 * sgn(d)
-    double cA = isshort ? cs : m.a_long;
-    o.w = cA * q;
-    o.q = q;
-    o.fac = isshort ? Ys : fabs(S);
-    o.isshort = isshort;
-    return o;
+    if (isshort) {
+        double Su = a.su * b.cu - a.cu * b.su;   // sin(k2 (z_a - z_b))
+        double Cu = a.cu * b.cu + a.su * b.su;
+        if (wrapped) {
+            // keep this a real (exec-masked) branch: as selects it costs four
+            // v_cndmask on top of the arithmetic
+            asm volatile("" ::: "memory");
+            // min image d = D - sgn(D) L; sgn(D) = sgn(S)
+            double t = __builtin_copysign(m.sth, S);
+            double sd = Su * m.cth - Cu * t;
+            double cd = Cu * m.cth + Su * t;
+            Su = sd;
+            Cu = cd;
+        }
+        // now (Su, Cu) = sin/cos(k2 d), |k2 d| < pi/2, sgn(Su) = sgn(d):
+        //   -k2 tan(k2 r - phi) sgn(d) = X / Y with
+        double t2 = __builtin_copysign(m.k2sphi, Su);
+        X = fma(m.m_k2cphi, Su, Cu * t2);
+        Y = fma(fabs(Su), m.sphi, Cu * m.cphi);
+    }
+    q = fast_div(X, Y);
+    Yout = Y;
 }
 
-// LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of 2*G*P doubles; the
-// entry of particle (lane g, register b) is stored at b*2G + g and b*2G + G + g
-// so a rotated read (g - k) never needs a modulo.
+// LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of 2*G*P
+// doubles; the entry of particle (lane g, register b) is stored at b*2G + g
+// and b*2G + G + g so a rotated read (g - k) never needs a modulo.
 template <int G, int P, bool ZCLASS>
 struct GroupLds {
     static constexpr int ROW = 2 * G * P;
@@ -241,12 +244,14 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
            *lCU = lds + 3 * ROW, *lZ = lds + 4 * ROW;
     const int n = m.n;
     PTab t[P];
+    double aks[P], akc[P];   // a_long * (sin, cos)(pi z / L)
     bool ok[P];
     double kin1[P];          // one-body kinetic + potential
-    double prod = 1.0;       // running product of positive factors (WF)
-    double lsum = 0.0;       // accumulated logs (WF)
+    double prodS = 1.0, prodL = 1.0;   // running products of pair factors (WF)
+    double prod1 = 1.0;      // product of the one-body factors (WF)
+    int expS = 0, expL = 0;  // binary exponents split off the products
     int nshort = 0, npair = 0;
-    double Qs = 0.0, Ql = 0.0; // sum of q^2 over short / long pairs
+    double Qall = 0.0, Qs = 0.0;  // sum of q^2 over all / short pairs
     double Kown[P], KT[P];   // per-particle pair kinetic sums (ITH)
     double T[P];             // travelling drift of the partner lane
 
@@ -254,9 +259,12 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     for (int a = 0; a < P; ++a) {
         ok[a] = !PAD || (gl + G * a) < n;
         F[a] = 0.0; kin1[a] = 0.0; T[a] = 0.0; Kown[a] = 0.0; KT[a] = 0.0;
+        aks[a] = 0.0; akc[a] = 0.0;
         if (!m.is_ideal) {
-            sincos(z[a] * m.pi_L, &t[a].s, &t[a].c);
-            sincos(z[a] * m.k2, &t[a].su, &t[a].cu);
+            sincos_halfpi(z[a] * m.two_over_L, t[a].s, t[a].c);
+            sincos_halfpi(z[a] * m.k2_2pi, t[a].su, t[a].cu);
+            aks[a] = m.a_long * t[a].s;
+            akc[a] = m.a_long * t[a].c;
             int i0 = a * 2 * G + gl;
             lS[i0] = t[a].s;   lS[i0 + G] = t[a].s;
             lC[i0] = t[a].c;   lC[i0 + G] = t[a].c;
@@ -270,11 +278,18 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             if (ok[a]) {
                 F[a] = ldz;
                 kin1[a] = kp;
-                if (WF) prod *= f1;
+                if (WF) prod1 *= f1;
             }
         }
     }
-    if (WF) { lsum = log(prod); prod = 1.0; }
+
+    // Split the binary exponent off a running product so that it can neither
+    // underflow nor overflow (one frexp pair instead of a log per fold).
+    auto fold = [](double &p, int &e) {
+        int de;
+        p = frexp(p, &de);
+        e += de;
+    };
 
     if (!m.is_ideal) {
         // make the table visible to the other lanes of the wave (one wave owns
@@ -283,24 +298,37 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        double prodL = 1.0;  // product of |sin| over long pairs (WF)
+        // sums that count every unordered pair once
+        auto tally = [&](double q, double Y, bool isshort) {
+            Qall = fma(q, q, Qall);
+            ++npair;
+            if (isshort) {
+                asm volatile("" ::: "memory");   // exec-masked, not selects
+                Qs = fma(q, q, Qs);
+                ++nshort;
+                if (WF) prodS *= Y;
+            } else {
+                if (WF) prodL *= fabs(Y);
+            }
+        };
+        auto pair_kin = [&](double q, bool isshort) {
+            return isshort ? fma(q, q, m.k2sq)
+                           : fma(q * q, m.inv_beta, m.b_long);
+        };
 
         // ---- k = 0: pairs inside the lane ----
 #pragma unroll
         for (int a = 0; a < P; ++a) {
 #pragma unroll
             for (int b = a + 1; b < P; ++b) {
-                PairOut o = pair_eval<ZCLASS>(m, t[a], z[a], t[b], z[b]);
-                bool v = ok[a] && ok[b];
-                if (v) {
-                    F[a] += o.w; F[b] -= o.w;
-                    if (o.isshort) { Qs = fma(o.q, o.q, Qs); ++nshort; }
-                    else           { Ql = fma(o.q, o.q, Ql); }
-                    ++npair;
-                    if (WF) { if (o.isshort) prod *= o.fac; else prodL *= o.fac; }
+                double q, Y; bool sh;
+                pair_core<ZCLASS>(m, t[a], aks[a], akc[a], z[a], t[b], z[b], q,
+                                  Y, sh);
+                if (!PAD || (ok[a] && ok[b])) {
+                    F[a] += q; F[b] -= q;
+                    tally(q, Y, sh);
                     if (ITH) {
-                        double cB = o.isshort ? m.k2sq : m.b_long;
-                        double kk = cB * fma(o.q, o.q, 1.0);
+                        double kk = pair_kin(q, sh);
                         Kown[a] += kk; Kown[b] += kk;
                     }
                 }
@@ -308,6 +336,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         }
 
         // ---- k = 1 .. G/2: rotate over partner lanes ----
+        const int lane = threadIdx.x & 63;
+        const int src = lane - gl + ((gl + G - 1) & (G - 1));
         for (int k = 1; k <= G / 2; ++k) {
             const bool last = (k == G / 2);
             const bool count_pair = !last || gl < G / 2;
@@ -327,45 +357,33 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             for (int a = 0; a < P; ++a) {
 #pragma unroll
                 for (int b = 0; b < P; ++b) {
-                    PairOut o = pair_eval<ZCLASS>(m, t[a], z[a], pb[b], pz[b]);
-                    bool v = ok[a] && pok[b];
-                    if (v) {
-                        F[a] += o.w;
-                        if (!last) T[b] -= o.w;
+                    double q, Y; bool sh;
+                    pair_core<ZCLASS>(m, t[a], aks[a], akc[a], z[a], pb[b],
+                                      pz[b], q, Y, sh);
+                    if (!PAD || (ok[a] && pok[b])) {
+                        F[a] += q;
+                        if (!last) T[b] -= q;
+                        if (count_pair) tally(q, Y, sh);
                         if (ITH) {
-                            double cB = o.isshort ? m.k2sq : m.b_long;
-                            double kk = cB * fma(o.q, o.q, 1.0);
+                            double kk = pair_kin(q, sh);
                             Kown[a] += kk;
                             if (!last) KT[b] += kk;
-                        }
-                        if (count_pair) {
-                            if (o.isshort) { Qs = fma(o.q, o.q, Qs); ++nshort; }
-                            else           { Ql = fma(o.q, o.q, Ql); }
-                            ++npair;
-                            if (WF) {
-                                if (o.isshort) prod *= o.fac;
-                                else prodL *= o.fac;
-                            }
                         }
                     }
                 }
             }
             if (!last) {
-                int src = (threadIdx.x & 63) - gl + ((gl + G - 1) & (G - 1));
 #pragma unroll
                 for (int b = 0; b < P; ++b) {
                     T[b] = __shfl(T[b], src, 64);
                     if (ITH) KT[b] = __shfl(KT[b], src, 64);
                 }
             }
-            // fold the running products into logs often enough that they
-            // can neither underflow nor overflow
-            if (WF && ((k & 3) == 0 || P > 2 || last)) {
-                lsum += log(prod) + m.beta * log(prodL);
-                prod = 1.0; prodL = 1.0;
+            if (WF && ((k & 7) == 0 || P > 1)) {
+                fold(prodS, expS);
+                fold(prodL, expL);
             }
         }
-        if (WF) lsum += (double)nshort * m.log_am;
         // deliver the travelling sums to their owners (lane gl ^ G/2 holds them)
 #pragma unroll
         for (int b = 0; b < P; ++b) {
@@ -384,13 +402,22 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             e_lane += e;
         }
     } else {
+        // sum over unordered pairs of (k2^2 + q^2) [short] and
+        // (b_long + q^2 / beta) [long], counted for both partners
         int nlong = npair - nshort;
-        e_lane = 2.0 * (m.k2sq * ((double)nshort + Qs) +
-                        m.b_long * ((double)nlong + Ql));
+        double pk = m.k2sq * (double)nshort + m.b_long * (double)nlong + Qs +
+                    (Qall - Qs) * m.inv_beta;
+        e_lane = 2.0 * pk;
 #pragma unroll
         for (int a = 0; a < P; ++a)
             if (ok[a]) e_lane += kin1[a] - F[a] * F[a];
     }
     E = group_sum<G>(e_lane);
-    if (WF) logwf = group_sum<G>(lsum);
+    if (WF) {
+        const double LN2 = 0.693147180559945309417;
+        double lw = log_pos(prod1 * prodS) + m.beta * log_pos(prodL) +
+                    LN2 * ((double)expS + m.beta * (double)expL) +
+                    (double)nshort * m.log_am;
+        logwf = group_sum<G>(lw);
+    }
 }

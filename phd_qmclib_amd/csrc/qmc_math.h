@@ -1,0 +1,138 @@
+// qmc_math.h -- fp64 elementary functions specialised for the walker engine.
+//
+// Every VALU instruction costs ~4 cycles per wave64 on gfx950 whatever its
+// width (measured, profiles/r01_v1_dmc64_pmc_summary.txt), so the engine's
+// speed is its instruction count.  The generic OCML routines carry argument
+// reduction for the whole double range (Payne-Hanek), denormal/inf/nan paths
+// and IEEE-exact division; the arguments here are bounded (positions in
+// [0, L), angles of a few pi, |x| < 40 for exp) and finite, so these versions
+// keep only what those ranges need.  Accuracy: <= 2 ulp, checked on the GPU
+// against the CPU oracle through the parity tests (2e-11 relative on every
+// energy / drift / log-psi).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+// q = x / y for normal, finite operands: hardware reciprocal estimate
+// (v_rcp_f64, ~2^-25 relative error), one Newton step on the reciprocal, one
+// correction of the quotient.  6 instructions against the 11 of the IEEE
+// sequence (v_div_scale x2, v_rcp, 4 fma, mul, fma, v_div_fmas, v_div_fixup).
+__device__ __forceinline__ double fast_div(double x, double y)
+{
+    double r = __builtin_amdgcn_rcp(y);
+    double e = fma(-y, r, 1.0);
+    r = fma(r, e, r);
+    double q = x * r;
+    double rem = fma(-y, q, x);
+    return fma(rem, r, q);
+}
+
+__device__ __forceinline__ double fast_rcp(double y)
+{
+    double r = __builtin_amdgcn_rcp(y);
+    double e = fma(-y, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-y, r, 1.0);
+    return fma(r, e, r);
+}
+
+// sin and cos on [-pi/4, pi/4]: the classic degree-13 / degree-14 minimax
+// kernels (coefficients of fdlibm's k_sin.c / k_cos.c, error < 2^-58).
+__device__ __forceinline__ void sincos_kernel(double x, double &s, double &c)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    s = fma(x * z, ps, x);
+    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    c = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
+
+// sin/cos of (pi/2) * u for a modest u (|u| < 2^20): quadrant split by
+// round-to-nearest, kernels on the remainder.  u = 2 z / L gives the angle
+// pi z / L with no cancellation; u = k2 z * (2/pi) gives k2 z.
+__device__ __forceinline__ void sincos_halfpi(double u, double &s, double &c)
+{
+    double q = rint(u);
+    double x = (u - q) * 1.57079632679489661923;   // |x| <= pi/4
+    double ks, kc;
+    sincos_kernel(x, ks, kc);
+    int iq = (int)q;
+    bool swap = iq & 1;
+    double a = swap ? kc : ks;       // |sin|
+    double b = swap ? ks : kc;       // |cos|
+    // quadrant signs: sin negative for q = 2, 3; cos negative for q = 1, 2
+    s = (iq & 2) ? -a : a;
+    c = ((iq + 1) & 2) ? -b : b;
+}
+
+// exp(x) for |x| < 700 (no overflow/denormal handling): n = rint(x / ln 2),
+// r = x - n ln2 (hi/lo split), degree-12 Taylor-minimax on |r| <= ln2/2.
+__device__ __forceinline__ double exp_bounded(double x)
+{
+    const double INV_LN2 = 1.44269504088896338700e+00;
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    double n = rint(x * INV_LN2);
+    double r = fma(-n, LN2_HI, x);
+    r = fma(-n, LN2_LO, r);
+    // exp(r) = sum r^k / k!, k <= 12: remainder (ln2/2)^13/13! ~ 1.7e-16
+    double p = 2.08767569878680989792e-09;            // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);        // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);        // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);        // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);        // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);        // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);        // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);        // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);        // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);        // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// log(x) for normal positive x: x = m 2^e with m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(s), s = (m-1)/(m+1), odd series in s (|s| < 0.1716) to s^21.
+__device__ __forceinline__ double log_pos(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    int e;
+    double m = frexp(x, &e);                 // m in [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    double s = fast_div(m - 1.0, m + 1.0);
+    double z = s * s;
+    double p = 1.0 / 21.0;
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    double lm = fma(s * z, 2.0 * p, 2.0 * s);
+    double de = (double)e;
+    return fma(de, LN2_HI, fma(de, LN2_LO, lm));
+}
+
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    // v_rsq_f64 estimate + two Newton steps (x > 0, normal)
+    double r = __builtin_amdgcn_rsq(x);
+    double g = x * r;
+    double h = 0.5 * r;
+    double d = fma(-h, g, 0.5);
+    g = fma(g, d, g);
+    h = fma(h, d, h);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}

@@ -199,6 +199,7 @@ vmc_block_kernel(DevModel m, VmcArgs a)
         // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
         const bool forced = (y == 0) && a.yield_initial;
         double zn[P];
+        double ua = 1.0;          // accept uniform (particle 0's spare double)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = gl + G * p;
@@ -209,14 +210,16 @@ vmc_block_kernel(DevModel m, VmcArgs a)
                     d = a.gaussian ? a.move_spread * tv
                                    : (tv - 0.5) * a.move_spread;
                 } else if (a.gaussian) {
-                    d = a.move_spread *
-                        philox_normal(a.seed, slot, step, (unsigned)i,
-                                      STREAM_VMC_MOVE);
+                    double g0, g1;
+                    philox_normal2(a.seed, slot, step, (unsigned)i,
+                                   STREAM_VMC_MOVE, g0, g1);
+                    d = a.move_spread * g0;
                 } else {
                     double u0, u1;
                     philox_uniform2(a.seed, slot, step, (unsigned)i,
                                     STREAM_VMC_MOVE, u0, u1);
                     d = (u0 - 0.5) * a.move_spread;
+                    if (p == 0) ua = u1;
                 }
             }
             // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
@@ -225,14 +228,16 @@ vmc_block_kernel(DevModel m, VmcArgs a)
         double F[P], ei[P], e_new, wf_new;
         eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
                                                 wf_new);
-        double ua = 1.0;
         if (!forced) {
             if (a.tape) {
                 ua = a.tape[(wr * a.tape_steps + treal) * (n + 1) + n];
-            } else {
+            } else if (a.gaussian) {
                 double u1;
                 philox_uniform2(a.seed, slot, step, 0u, STREAM_VMC_ACCEPT, ua,
                                 u1);
+            } else {
+                // lane 0 of the group holds particle 0
+                ua = __shfl(ua, (threadIdx.x & 63) - gl, 64);
             }
         }
         // Metropolis test (qmc_base/vmc.py:636)
@@ -283,6 +288,7 @@ struct DmcCtl {
     double ref_energy;
     double total_energy, total_weight;
     double e_t, w_t;        // estimators of this step (local or global)
+    long long spare_nw;     // slots holding a valid spare normal
     unsigned int step;
     unsigned int pad;
 };
@@ -452,6 +458,7 @@ struct EvolveArgs {
     const long long *ref;
     const DmcCtl *ctl;
     const double *g_tape;     // [slot][N] standard normals or null
+    double *spare;            // [maxw][N] second Box-Muller normal of a pair
     long long maxw;
     double dt, sigma;
     unsigned long long seed;
@@ -478,6 +485,8 @@ dmc_evolve_kernel(DevModel m, EvolveArgs a)
     const int n = m.n;
     const unsigned int step = a.ctl->step;
     const double ref_energy = a.ctl->ref_energy;
+    // slots that existed at the previous (even) step have a stored normal
+    const long long spare_nw = a.ctl->spare_nw;
     const long long par = a.ref[sr];
 
     double z[P];
@@ -488,10 +497,21 @@ dmc_evolve_kernel(DevModel m, EvolveArgs a)
         if (i < n) {
             double z0 = a.ppos[par * n + i];
             double f0 = a.pdrift[par * n + i];
-            double g = a.g_tape ? a.g_tape[sr * n + i]
-                                : philox_normal(a.seed, a.slot0 + (unsigned)sr,
-                                                step, (unsigned)i,
-                                                STREAM_DMC_DIFFUSE);
+            double g;
+            if (a.g_tape) {
+                g = a.g_tape[sr * n + i];
+            } else if ((step & 1u) && sr < spare_nw) {
+                // odd step: the sine-branch normal stored by the even step
+                g = a.spare[sr * n + i];
+            } else {
+                // time steps 2m, 2m+1 share one Philox block: cosine branch
+                // now, sine branch kept for the next step of this slot
+                double g0, g1;
+                philox_normal2(a.seed, a.slot0 + (unsigned)sr, step >> 1,
+                               (unsigned)i, STREAM_DMC_DIFFUSE, g0, g1);
+                g = (step & 1u) ? g1 : g0;
+                if (!(step & 1u) && active) a.spare[sr * n + i] = g1;
+            }
             // ith_diffusion (qmc_base/jastrow/dmc.py:661-671)
             double zn = z0 + 2 * f0 * a.dt + a.sigma * g;
             zz = wrap_box(zn, m.L);
@@ -551,6 +571,9 @@ __global__ void dmc_finish_kernel(FinishArgs a)
         a.ser_ref[a.ser_idx] = ref;
         a.ser_acc[a.ser_idx] = accum;
     }
+    // an even step stored spare normals for slots [0, nw); they are consumed
+    // by the next (odd) step and invalid afterwards
+    c->spare_nw = (c->step & 1u) ? 0 : c->nw;
     c->prev_nw = c->nw;
     c->step += 1;
 }
@@ -720,25 +743,31 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.half_L = 0.5 * d.L;
     d.rm = fabs(p.tbf_contact_cutoff);
     d.L_minus_rm = d.L - d.rm;
-    d.pi_L = QMC_PI / d.L;
+    d.two_over_L = 2.0 / d.L;
+    d.k2_2pi = p.param_k2 * (2.0 / QMC_PI);
     d.k2 = p.param_k2;
     d.k2sq = d.k2 * d.k2;
     double phi = p.param_k2 * p.param_r_off;
     d.cphi = cos(phi);
     d.sphi = sin(phi);
+    d.m_k2cphi = -d.k2 * d.cphi;
+    d.k2sphi = d.k2 * d.sphi;
     double th = p.param_k2 * d.L;
     d.cth = cos(th);
     d.sth = sin(th);
     d.sin_rm = (d.rm >= d.half_L) ? 1.0 : sin(QMC_PI * d.rm / d.L);
     // sin(pi r / L) is flat near r = L/2: classify from positions there
     d.zclass = d.rm > 0.45 * d.L;
-    d.a_long = d.pi_L * p.param_beta;
-    d.b_long = d.pi_L * d.pi_L * p.param_beta;
+    double pi_L = QMC_PI / d.L;
+    d.a_long = pi_L * p.param_beta;
+    d.b_long = pi_L * pi_L * p.param_beta;
     d.beta = p.param_beta;
+    d.inv_beta = p.param_beta != 0.0 ? 1.0 / p.param_beta : 0.0;
     d.log_am = log(fabs(p.param_am));
     d.z_a = 1.0 / (1.0 + p.lattice_ratio);
     d.z_b = p.lattice_ratio / (1.0 + p.lattice_ratio);
     d.k1 = p.param_k1;
+    d.k1_2pi = p.param_k1 * (2.0 / QMC_PI);
     d.kp1 = p.param_kp1;
     d.e0 = p.param_e0;
     d.v0 = p.lattice_depth;
@@ -1046,6 +1075,7 @@ struct qmc_dmc {
     double *energy[2] = { nullptr, nullptr }, *weight[2] = { nullptr, nullptr };
     int cur = 0;                 // index of the parent buffer
     double *eslot = nullptr;
+    double *spare = nullptr;
     long long *ref = nullptr;
     int *count = nullptr;
     long long *block_tot = nullptr, *block_off = nullptr;
@@ -1097,7 +1127,8 @@ extern "C" int qmc_dmc_create(qmc_engine *e, const qmc_dmc_params *p,
         rc |= dev_alloc(&d->pos[b], W * n) || dev_alloc(&d->drift[b], W * n) ||
               dev_alloc(&d->energy[b], W) || dev_alloc(&d->weight[b], W);
     }
-    rc = rc || dev_alloc(&d->eslot, W) || dev_alloc(&d->ref, W) ||
+    rc = rc || dev_alloc(&d->eslot, W) || dev_alloc(&d->spare, W * n) ||
+         dev_alloc(&d->ref, W) ||
          dev_alloc(&d->count, W) || dev_alloc(&d->block_tot, d->nblocks) ||
          dev_alloc(&d->block_off, d->nblocks) ||
          dev_alloc(&d->block_esum, d->nblocks) || dev_alloc(&d->ctl, 1);
@@ -1117,7 +1148,7 @@ extern "C" void qmc_dmc_destroy(qmc_dmc *d)
         hipFree(d->pos[b]); hipFree(d->drift[b]);
         hipFree(d->energy[b]); hipFree(d->weight[b]);
     }
-    hipFree(d->eslot); hipFree(d->ref); hipFree(d->count);
+    hipFree(d->eslot); hipFree(d->spare); hipFree(d->ref); hipFree(d->count);
     hipFree(d->block_tot); hipFree(d->block_off); hipFree(d->block_esum);
     hipFree(d->ctl);
     if (d->ser_e) { hipFree(d->ser_e); hipFree(d->ser_w); hipFree(d->ser_ref);
@@ -1288,6 +1319,7 @@ static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev)
     a.cpos = d->pos[chi]; a.cdrift = d->drift[chi];
     a.cenergy = d->energy[chi]; a.cweight = d->weight[chi];
     a.eslot = d->eslot; a.ref = d->ref; a.ctl = d->ctl; a.g_tape = gt;
+    a.spare = d->spare;
     a.maxw = d->maxw; a.dt = d->p.time_step;
     a.sigma = sqrt(2 * d->p.time_step);           // mrbp_qmc/dmc.py:178
     a.seed = d->p.rng_seed; a.slot0 = d->p.slot0;
