@@ -47,7 +47,7 @@ def main():
     ap.add_argument('--steps', type=int, default=64)
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--block', type=int, default=16,
-                    help='Metropolis steps per kernel launch')
+                    help='Metropolis steps enqueued per block call')
     ap.add_argument('--bosons', type=int, default=64)
     ap.add_argument('--chains', type=int, default=1 << 20,
                     help='VMC chains per GPU')
@@ -93,14 +93,14 @@ def main():
     del pos
 
     def run_steps(k):
+        # one kernel launch per Metropolis step (the block call enqueues
+        # `b` launches without a host synchronisation)
         done = 0
-        launches = 0
         while done < k:
             b = min(args.block, k - done)
             vmc.run_block(b, sums=False)
             done += b
-            launches += 1
-        return launches
+        return k
 
     run_steps(args.warmup)
     barrier()
@@ -149,14 +149,14 @@ def main():
         'config': {
             'workload': f'mrbp_qmc VMC, N={n} bosons, {W} chains per GPU, '
                         f'move_spread=0.25*well_width, energy on accepted moves',
-            'bosons': n, 'chains_per_gpu': W, 'steps_per_launch': args.block,
+            'bosons': n, 'chains_per_gpu': W, 'steps_per_launch': 1,
             'parallelism': f'chains sharded over {world} GPU(s), no data-path '
                            f'collective',
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-            'kernel': 'vmc_block_kernel', 'launch_ms': launch_ms,
+            'kernel': 'vmc_step_kernel', 'launch_ms': launch_ms,
             'bytes_per_unit': b_vmc,
         },
         'extra': {

@@ -199,7 +199,7 @@ __device__ __forceinline__ void pair_core(const DevModel &m, const PTab &a,
         if (wrapped) {
             // keep this a real (exec-masked) branch: as selects it costs four
             // v_cndmask on top of the arithmetic
-            asm volatile("" ::: "memory");
+            asm volatile("");
             // min image d = D - sgn(D) L; sgn(D) = sgn(S)
             double t = __builtin_copysign(m.sth, S);
             double sd = Su * m.cth - Cu * t;
@@ -285,11 +285,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 
     // Split the binary exponent off a running product so that it can neither
     // underflow nor overflow (one frexp pair instead of a log per fold).
-    auto fold = [](double &p, int &e) {
-        int de;
-        p = frexp(p, &de);
-        e += de;
-    };
+#define QMC_FOLD(p, e)                                                        \
+    do {                                                                      \
+        e += __builtin_amdgcn_frexp_exp(p);                                   \
+        p = __builtin_amdgcn_frexp_mant(p);                                   \
+    } while (0)
 
     if (!m.is_ideal) {
         // make the table visible to the other lanes of the wave (one wave owns
@@ -299,22 +299,21 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // sums that count every unordered pair once
-        auto tally = [&](double q, double Y, bool isshort) {
-            Qall = fma(q, q, Qall);
-            ++npair;
-            if (isshort) {
-                asm volatile("" ::: "memory");   // exec-masked, not selects
-                Qs = fma(q, q, Qs);
-                ++nshort;
-                if (WF) prodS *= Y;
-            } else {
-                if (WF) prodL *= fabs(Y);
-            }
-        };
-        auto pair_kin = [&](double q, bool isshort) {
-            return isshort ? fma(q, q, m.k2sq)
-                           : fma(q * q, m.inv_beta, m.b_long);
-        };
+#define QMC_TALLY(q, Y, isshort)                                              \
+    do {                                                                      \
+        Qall = fma(q, q, Qall);                                               \
+        ++npair;                                                              \
+        if (isshort) {                                                        \
+            asm volatile("");   /* exec-masked, not selects */                \
+            Qs = fma(q, q, Qs);                                               \
+            ++nshort;                                                         \
+            if (WF) prodS *= Y;                                               \
+        } else {                                                              \
+            if (WF) { asm volatile(""); prodL *= fabs(Y); }                   \
+        }                                                                     \
+    } while (0)
+#define QMC_PAIR_KIN(q, isshort)                                              \
+    ((isshort) ? fma(q, q, m.k2sq) : fma((q) * (q), m.inv_beta, m.b_long))
 
         // ---- k = 0: pairs inside the lane ----
 #pragma unroll
@@ -326,9 +325,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                                   Y, sh);
                 if (!PAD || (ok[a] && ok[b])) {
                     F[a] += q; F[b] -= q;
-                    tally(q, Y, sh);
+                    QMC_TALLY(q, Y, sh);
                     if (ITH) {
-                        double kk = pair_kin(q, sh);
+                        double kk = QMC_PAIR_KIN(q, sh);
                         Kown[a] += kk; Kown[b] += kk;
                     }
                 }
@@ -363,9 +362,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                     if (!PAD || (ok[a] && pok[b])) {
                         F[a] += q;
                         if (!last) T[b] -= q;
-                        if (count_pair) tally(q, Y, sh);
+                        if (count_pair) { QMC_TALLY(q, Y, sh); }
                         if (ITH) {
-                            double kk = pair_kin(q, sh);
+                            double kk = QMC_PAIR_KIN(q, sh);
                             Kown[a] += kk;
                             if (!last) KT[b] += kk;
                         }
@@ -380,8 +379,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 }
             }
             if (WF && ((k & 7) == 0 || P > 1)) {
-                fold(prodS, expS);
-                fold(prodL, expL);
+                QMC_FOLD(prodS, expS);
+                QMC_FOLD(prodL, expL);
             }
         }
         // deliver the travelling sums to their owners (lane gl ^ G/2 holds them)
@@ -420,4 +419,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                     (double)nshort * m.log_am;
         logwf = group_sum<G>(lw);
     }
+#undef QMC_FOLD
+#undef QMC_TALLY
+#undef QMC_PAIR_KIN
 }

@@ -47,6 +47,7 @@ struct qmc_engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevModel dm;
+    DevModel *dm_dev = nullptr;
     qmc_model_params mp;
     int G = 64, P = 1;
     bool pad = false;
@@ -79,8 +80,11 @@ struct EvalArgs {
 
 template <int G, int P, bool PAD, bool ZC>
 __global__ void __launch_bounds__(BLOCK)
-evaluate_kernel(DevModel m, EvalArgs a)
+evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
 {
+    // model constants live in device memory: scalar loads on demand keep the
+    // SGPR file free for the hot loop (by-value they overflow it)
+    const DevModel &m = *mp;
     extern __shared__ double smem[];
     constexpr int GPB = BLOCK / G;            // groups per block
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
@@ -120,8 +124,11 @@ struct PrepArgs {
 
 template <int G, int P, bool PAD, bool ZC>
 __global__ void __launch_bounds__(BLOCK)
-prepare_kernel(DevModel m, PrepArgs a)
+prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
 {
+    // model constants live in device memory: scalar loads on demand keep the
+    // SGPR file free for the hot loop (by-value they overflow it)
+    const DevModel &m = *mp;
     extern __shared__ double smem[];
     constexpr int GPB = BLOCK / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
@@ -145,32 +152,42 @@ prepare_kernel(DevModel m, PrepArgs a)
     if (gl == 0) a.energy[w] = E;
 }
 
-// ---- VMC: one launch advances every chain by a whole block of yields ----
+// ---- VMC: one launch = one generator yield of every chain ----------------
+// (a step loop inside the kernel lets LICM hoist ~40 polynomial constants and
+// the model constants across it, tripling the register count; with the loop on
+// the host the kernel has the register footprint of `evaluate_kernel` and the
+// state round trip is ~1 KB per chain-step, far below the HBM roofline.)
 struct VmcArgs {
     double *pos;          // [W][N] in/out
     double *wf;           // [W]    in/out  log|psi|
     double *ecarry;       // [W]    in/out  energy carried to rejected moves
-    double *sum_e, *sum_e2;
+    double *sum_e, *sum_e2;   // [W] running block sums
     long long *n_acc;
     double *ser_wf, *ser_e;   // [nyield][W] or null
     unsigned char *ser_stat;
     double *ser_pos;          // [nyield][W][N] or null
     const double *tape;   // [W][tape_steps][N+1] or null
     long long tape_steps;
+    long long tape_idx;   // real step index into the tape for this yield
     long long W;
-    long long nyield;
-    int yield_initial;
+    long long y;          // yield index inside the block (series row)
+    int forced;           // this yield is the initial state (ACCEPTED)
+    int reset_sums;       // first yield of a block: sums start from zero
     int gaussian;
-    unsigned int step0;
+    unsigned int step;    // Philox step counter of this yield
     unsigned int chain0;
     unsigned long long seed;
     double move_spread;
 };
 
-template <int G, int P, bool PAD, bool ZC>
+// LEAN = the production path (Philox uniform proposal, per-chain block sums
+// only); the full variant adds the test-only tape replay, the Gaussian
+// proposal and the per-step series.
+template <int G, int P, bool PAD, bool ZC, bool LEAN>
 __global__ void __launch_bounds__(BLOCK)
-vmc_block_kernel(DevModel m, VmcArgs a)
+vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 {
+    const DevModel &m = *mp;
     extern __shared__ double smem[];
     constexpr int GPB = BLOCK / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
@@ -179,104 +196,90 @@ vmc_block_kernel(DevModel m, VmcArgs a)
     const bool active = w < a.W;
     const long long wr = active ? w : 0;
     const int n = m.n;
+    const unsigned int slot = a.chain0 + (unsigned int)wr;
+    // The very first yield of a generator is the initial state itself,
+    // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
+    const bool forced = a.forced != 0;
 
-    double z[P];
+    double z[P], zn[P];
+    double ua = 1.0;          // accept uniform (particle 0's spare double)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = gl + G * p;
         z[p] = (i < n) ? a.pos[wr * n + i] : 0.0;
+        double d = 0.0;
+        if (!forced && i < n) {
+            if (!LEAN && a.tape) {
+                double tv = a.tape[(wr * a.tape_steps + a.tape_idx) * (n + 1) + i];
+                d = a.gaussian ? a.move_spread * tv
+                               : (tv - 0.5) * a.move_spread;
+            } else if (!LEAN && a.gaussian) {
+                double g0, g1;
+                philox_normal2(a.seed, slot, a.step, (unsigned)i,
+                               STREAM_VMC_MOVE, g0, g1);
+                d = a.move_spread * g0;
+            } else {
+                double u0, u1;
+                philox_uniform2(a.seed, slot, a.step, (unsigned)i,
+                                STREAM_VMC_MOVE, u0, u1);
+                d = (u0 - 0.5) * a.move_spread;
+                if (p == 0) ua = u1;
+            }
+        }
+        // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
+        zn[p] = forced ? z[p] : wrap_box(z[p] + d, m.L);
     }
-    double wf_cur = a.wf[wr];
-    double e_cur = a.ecarry[wr];
-    double se = 0.0, se2 = 0.0;
-    long long nacc = 0;
-    unsigned int step = a.step0;
-    const unsigned int slot = a.chain0 + (unsigned int)wr;
-    long long treal = 0;      // real steps done in this launch (tape index)
-
-    for (long long y = 0; y < a.nyield; ++y) {
-        // The very first yield of a generator is the initial state itself,
-        // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
-        const bool forced = (y == 0) && a.yield_initial;
-        double zn[P];
-        double ua = 1.0;          // accept uniform (particle 0's spare double)
+    double F[P], ei[P], e_new, wf_new;
+    eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
+                                            wf_new);
+    if (!forced) {
+        if (!LEAN && a.tape) {
+            ua = a.tape[(wr * a.tape_steps + a.tape_idx) * (n + 1) + n];
+        } else if (!LEAN && a.gaussian) {
+            double u1;
+            philox_uniform2(a.seed, slot, a.step, 0u, STREAM_VMC_ACCEPT, ua,
+                            u1);
+        } else {
+            // lane 0 of the group holds particle 0
+            ua = __shfl(ua, (threadIdx.x & 63) - gl, 64);
+        }
+    }
+    if (!active) return;
+    double wf_cur = a.wf[w];
+    double e_cur = a.ecarry[w];
+    // Metropolis test (qmc_base/vmc.py:636)
+    const bool acc = forced || ua <= 0.0 ||
+                     (wf_new > 0.5 * log_pos(ua) + wf_cur);
+    if (acc) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = gl + G * p;
-            double d = 0.0;
-            if (!forced && i < n) {
-                if (a.tape) {
-                    double tv = a.tape[(wr * a.tape_steps + treal) * (n + 1) + i];
-                    d = a.gaussian ? a.move_spread * tv
-                                   : (tv - 0.5) * a.move_spread;
-                } else if (a.gaussian) {
-                    double g0, g1;
-                    philox_normal2(a.seed, slot, step, (unsigned)i,
-                                   STREAM_VMC_MOVE, g0, g1);
-                    d = a.move_spread * g0;
-                } else {
-                    double u0, u1;
-                    philox_uniform2(a.seed, slot, step, (unsigned)i,
-                                    STREAM_VMC_MOVE, u0, u1);
-                    d = (u0 - 0.5) * a.move_spread;
-                    if (p == 0) ua = u1;
-                }
-            }
-            // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
-            zn[p] = forced ? z[p] : wrap_box(z[p] + d, m.L);
+            if (i < n && !forced) a.pos[w * n + i] = zn[p];
         }
-        double F[P], ei[P], e_new, wf_new;
-        eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
-                                                wf_new);
-        if (!forced) {
-            if (a.tape) {
-                ua = a.tape[(wr * a.tape_steps + treal) * (n + 1) + n];
-            } else if (a.gaussian) {
-                double u1;
-                philox_uniform2(a.seed, slot, step, 0u, STREAM_VMC_ACCEPT, ua,
-                                u1);
-            } else {
-                // lane 0 of the group holds particle 0
-                ua = __shfl(ua, (threadIdx.x & 63) - gl, 64);
-            }
-        }
-        // Metropolis test (qmc_base/vmc.py:636)
-        const bool acc = forced || (wf_new > 0.5 * log(ua) + wf_cur);
-        if (acc) {
+        if (!forced) wf_cur = wf_new;
+        e_cur = e_new;       // energy only re-evaluated on accepted moves
+    }                        // (qmc_base/jastrow/vmc.py:253-262)
+    if (!LEAN && a.ser_pos) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) z[p] = zn[p];
-            if (!forced) wf_cur = wf_new;
-            e_cur = e_new;   // energy only re-evaluated on accepted moves
-            ++nacc;          // (qmc_base/jastrow/vmc.py:253-262)
+        for (int p = 0; p < P; ++p) {
+            int i = gl + G * p;
+            if (i < n) a.ser_pos[(a.y * a.W + w) * n + i] = acc ? zn[p] : z[p];
         }
-        se += e_cur;
-        se2 += e_cur * e_cur;
-        if (active && gl == 0) {
-            if (a.ser_wf) a.ser_wf[y * a.W + w] = wf_cur;
-            if (a.ser_e) a.ser_e[y * a.W + w] = e_cur;
-            if (a.ser_stat) a.ser_stat[y * a.W + w] = acc ? 1 : 0;
-        }
-        if (active && a.ser_pos) {
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                int i = gl + G * p;
-                if (i < n) a.ser_pos[(y * a.W + w) * n + i] = z[p];
-            }
-        }
-        if (!forced) { ++step; ++treal; }
-    }
-    if (!active) return;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
-        if (i < n) a.pos[w * n + i] = z[p];
     }
     if (gl == 0) {
+        double se = a.reset_sums ? 0.0 : a.sum_e[w];
+        double se2 = a.reset_sums ? 0.0 : a.sum_e2[w];
+        long long na = a.reset_sums ? 0 : a.n_acc[w];
         a.wf[w] = wf_cur;
         a.ecarry[w] = e_cur;
-        a.sum_e[w] = se;
-        a.sum_e2[w] = se2;
-        a.n_acc[w] = nacc;
+        a.sum_e[w] = se + e_cur;
+        a.sum_e2[w] = fma(e_cur, e_cur, se2);
+        a.n_acc[w] = na + (acc ? 1 : 0);
+        if (!LEAN) {
+            if (a.ser_wf) a.ser_wf[a.y * a.W + w] = wf_cur;
+            if (a.ser_e) a.ser_e[a.y * a.W + w] = e_cur;
+            if (a.ser_stat) a.ser_stat[a.y * a.W + w] = acc ? 1 : 0;
+        }
     }
 }
 
@@ -470,8 +473,11 @@ struct EvolveArgs {
 // (qmc_base/jastrow/dmc.py:758-825, 892-942).
 template <int G, int P, bool PAD, bool ZC>
 __global__ void __launch_bounds__(BLOCK)
-dmc_evolve_kernel(DevModel m, EvolveArgs a)
+dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
 {
+    // model constants live in device memory: scalar loads on demand keep the
+    // SGPR file free for the hot loop (by-value they overflow it)
+    const DevModel &m = *mp;
     extern __shared__ double smem[];
     constexpr int GPB = BLOCK / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
@@ -682,7 +688,7 @@ struct LaunchEval {
         allow_lds(evaluate_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((evaluate_kernel<G, P, PAD, ZC>),
                            dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
-                           lds, e->stream, e->dm, a);
+                           lds, e->stream, e->dm_dev, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -697,7 +703,7 @@ struct LaunchPrep {
         allow_lds(prepare_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((prepare_kernel<G, P, PAD, ZC>),
                            dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
-                           lds, e->stream, e->dm, a);
+                           lds, e->stream, e->dm_dev, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -708,10 +714,19 @@ struct LaunchVmc {
     static int run(const qmc_engine *e, const VmcArgs &a)
     {
         const size_t lds = lds_bytes<G, P, ZC>();
-        allow_lds(vmc_block_kernel<G, P, PAD, ZC>, lds);
-        hipLaunchKernelGGL((vmc_block_kernel<G, P, PAD, ZC>),
-                           dim3(grid_for<G>(a.W)), dim3(BLOCK),
-                           lds, e->stream, e->dm, a);
+        const bool lean = !a.tape && !a.gaussian && !a.ser_wf && !a.ser_e &&
+                          !a.ser_stat && !a.ser_pos;
+        if (lean) {
+            allow_lds(vmc_step_kernel<G, P, PAD, ZC, true>, lds);
+            hipLaunchKernelGGL((vmc_step_kernel<G, P, PAD, ZC, true>),
+                               dim3(grid_for<G>(a.W)), dim3(BLOCK), lds,
+                               e->stream, e->dm_dev, a);
+        } else {
+            allow_lds(vmc_step_kernel<G, P, PAD, ZC, false>, lds);
+            hipLaunchKernelGGL((vmc_step_kernel<G, P, PAD, ZC, false>),
+                               dim3(grid_for<G>(a.W)), dim3(BLOCK), lds,
+                               e->stream, e->dm_dev, a);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -725,7 +740,7 @@ struct LaunchEvolve {
         allow_lds(dmc_evolve_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((dmc_evolve_kernel<G, P, PAD, ZC>),
                            dim3(grid_for<G>(a.maxw)), dim3(BLOCK),
-                           lds, e->stream, e->dm, a);
+                           lds, e->stream, e->dm_dev, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -807,6 +822,9 @@ extern "C" int qmc_engine_create(const qmc_model_params *model, int device,
     }
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
+    HIP_TRY(hipMalloc((void **)&e->dm_dev, sizeof(DevModel)));
+    HIP_TRY(hipMemcpy(e->dm_dev, &e->dm, sizeof(DevModel),
+                      hipMemcpyHostToDevice));
     *out = e;
     return 0;
 }
@@ -817,6 +835,7 @@ extern "C" void qmc_engine_destroy(qmc_engine *e)
     hipSetDevice(e->device);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->dm_dev) hipFree(e->dm_dev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1028,17 +1047,22 @@ extern "C" int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_e,
     a.pos = v->pos; a.wf = v->wf; a.ecarry = v->ecarry;
     a.sum_e = v->sum_e; a.sum_e2 = v->sum_e2; a.n_acc = v->n_acc;
     a.ser_wf = dwf; a.ser_e = de; a.ser_stat = dst; a.ser_pos = dpos;
-    a.tape = v->tape ? v->tape + (size_t)v->tape_used * (e->dm.n + 1) : nullptr;
+    a.tape = v->tape;
     a.tape_steps = v->tape_steps;
-    a.W = v->W; a.nyield = nyield;
-    a.yield_initial = v->yield_initial;
+    a.W = v->W;
     a.gaussian = v->p.gaussian;
-    a.step0 = v->step; a.chain0 = v->p.chain0;
+    a.chain0 = v->p.chain0;
     a.seed = v->p.rng_seed; a.move_spread = v->p.move_spread;
-    int rc = dispatch_shape<LaunchVmc>(e, a);
-    if (rc) return rc;
-    v->step += (unsigned int)real;
-    v->tape_used += real;
+    for (long long y = 0; y < nyield; ++y) {
+        a.y = y;
+        a.forced = (y == 0 && v->yield_initial) ? 1 : 0;
+        a.reset_sums = (y == 0) ? 1 : 0;
+        a.step = v->step;
+        a.tape_idx = v->tape_used;
+        int rc = dispatch_shape<LaunchVmc>(e, a);
+        if (rc) return rc;
+        if (!a.forced) { v->step += 1; v->tape_used += 1; }
+    }
     v->yield_initial = 0;
     bool need_sync = false;
     if (sum_e) { HIP_TRY(hipMemcpyAsync(sum_e, v->sum_e, W * sizeof(double),
