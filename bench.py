@@ -133,6 +133,18 @@ def main():
     pairs = n * (n - 1) // 2
     pair_rate = W * args.steps * pairs / (kernel_ms * 1e-3)
 
+    # measured HBM traffic per chain-step (rocprofv3 FETCH_SIZE/WRITE_SIZE passes,
+    # profiles/r01_traffic.json), scaled to the units of one launch
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fp:
+            tj = json.load(fp)
+        if n == 64:
+            traffic = tj['vmc_step_kernel_bytes_per_chain_step_N64'] * W * \
+                steps_per_launch
+    except (OSError, KeyError, ValueError):
+        pass
+
     out = {
         'metric': 'walker-steps/sec',
         'value': value,
@@ -155,7 +167,7 @@ def main():
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
             'kernel': 'vmc_step_kernel', 'launch_ms': launch_ms,
             'bytes_per_unit': b_vmc,
         },
@@ -202,7 +214,9 @@ def main():
     if not args.no_cpu and rank == 0:
         from oracle import qmc_oracle as orc
         m = orc.model_from_cfc(cfc)
-        cores = orc.max_threads()
+        # the one-GPU box shares its host: use its CPU allotment, not every
+        # hardware thread the kernel reports
+        cores = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0)), 16))
         rng = np.random.RandomState(7)
         wc, ns = 64 * cores, 4
         cpos = spec.supercell_size * rng.random_sample((wc, n))
