@@ -169,6 +169,26 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
     }
 }
 
+// Constants of the pair loop, loaded once per walker evaluation.  The two that
+// feed a copysign live in VGPRs (a v_bfi on the high dword then needs no move
+// of the low dword from an SGPR every pair).
+struct PairConsts {
+    double sin_rm, cth, m_k2cphi, sphi, cphi;
+    double v_sth, v_k2sphi;       // VGPR-resident
+    double half_L, rm, L_minus_rm;
+};
+
+__device__ __forceinline__ PairConsts load_pair_consts(const DevModel &m)
+{
+    PairConsts c;
+    c.sin_rm = m.sin_rm; c.cth = m.cth; c.m_k2cphi = m.m_k2cphi;
+    c.sphi = m.sphi; c.cphi = m.cphi;
+    c.half_L = m.half_L; c.rm = m.rm; c.L_minus_rm = m.L_minus_rm;
+    c.v_sth = m.sth; c.v_k2sphi = m.k2sphi;
+    asm volatile("" : "+v"(c.v_sth), "+v"(c.v_k2sphi));
+    return c;
+}
+
 // One pair, seen from the own particle (table `a`, long-range numerator
 // coefficients aks/akc = a_long * (sin, cos)) against partner table `b`.
 //   q       : contribution to the drift of the own particle (partner: -q)
@@ -176,10 +196,11 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
 //             (short: cos(k2 r - phi); long: sin(pi d / L), signed)
 //   isshort : r < rm
 template <bool ZCLASS>
-__device__ __forceinline__ void pair_core(const DevModel &m, const PTab &a,
+__device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
                                           double aks, double akc, double za,
                                           const PTab &b, double zb, double &q,
-                                          double &Yout, bool &isshort)
+                                          double &Yout, bool &isshort,
+                                          unsigned long long &shortmask)
 {
     double S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
     double X = akc * b.c + aks * b.s;     // a_long * cos(...)
@@ -193,6 +214,9 @@ __device__ __forceinline__ void pair_core(const DevModel &m, const PTab &a,
         wrapped = X < 0.0;                // |z_a - z_b| > L/2
         isshort = fabs(S) < m.sin_rm;     // min-image r < rm
     }
+    // taken here, in the block of the compare, the ballot is the compare's own
+    // SGPR mask (later it costs a v_cndmask + v_cmp round trip)
+    shortmask = __ballot(isshort);
     if (isshort) {
         double Su = a.su * b.cu - a.cu * b.su;   // sin(k2 (z_a - z_b))
         double Cu = a.cu * b.cu + a.su * b.su;
@@ -201,19 +225,25 @@ __device__ __forceinline__ void pair_core(const DevModel &m, const PTab &a,
             // v_cndmask on top of the arithmetic
             asm volatile("");
             // min image d = D - sgn(D) L; sgn(D) = sgn(S)
-            double t = __builtin_copysign(m.sth, S);
-            double sd = Su * m.cth - Cu * t;
-            double cd = Cu * m.cth + Su * t;
-            Su = sd;
-            Cu = cd;
+            double t = __builtin_copysign(m.v_sth, S);
+            double ct, st;
+            const double cth = m.cth;
+            // in place, exactly four instructions (the compiler's two-address
+            // v_fmac form needs two extra 64-bit moves at the join)
+            asm("v_mul_f64 %[ct], %[cu], %[t]\n\t"
+                "v_mul_f64 %[st], %[su], %[t]\n\t"
+                "v_fma_f64 %[su], %[su], %[cth], -%[ct]\n\t"
+                "v_fma_f64 %[cu], %[cu], %[cth], %[st]"
+                : [su] "+v"(Su), [cu] "+v"(Cu), [ct] "=&v"(ct), [st] "=&v"(st)
+                : [t] "v"(t), [cth] "s"(cth));
         }
         // now (Su, Cu) = sin/cos(k2 d), |k2 d| < pi/2, sgn(Su) = sgn(d):
         //   -k2 tan(k2 r - phi) sgn(d) = X / Y with
-        double t2 = __builtin_copysign(m.k2sphi, Su);
+        double t2 = __builtin_copysign(m.v_k2sphi, Su);
         X = fma(m.m_k2cphi, Su, Cu * t2);
         Y = fma(fabs(Su), m.sphi, Cu * m.cphi);
     }
-    q = fast_div(X, Y);
+    q = pair_div(X, Y);
     Yout = Y;
 }
 
@@ -251,6 +281,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     double prod1 = 1.0;      // product of the one-body factors (WF)
     int expS = 0, expL = 0;  // binary exponents split off the products
     int nshort = 0, npair = 0;
+    // one walker per wavefront and no padding: short pairs are counted with a
+    // ballot + scalar popcount (SALU) instead of a per-lane VALU add
+    constexpr bool WAVE_COUNT = (G == 64) && !PAD;
+    int ns_wave = 0;
     double Qall = 0.0, Qs = 0.0;  // sum of q^2 over all / short pairs
     double Kown[P], KT[P];   // per-particle pair kinetic sums (ITH)
     double T[P];             // travelling drift of the partner lane
@@ -292,6 +326,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     } while (0)
 
     if (!m.is_ideal) {
+        const PairConsts pc = load_pair_consts(m);
         // make the table visible to the other lanes of the wave (one wave owns
         // its groups' LDS region: LDS ops of a wave complete in order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -302,11 +337,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 #define QMC_TALLY(q, Y, isshort)                                              \
     do {                                                                      \
         Qall = fma(q, q, Qall);                                               \
-        ++npair;                                                              \
+        if (!WAVE_COUNT) ++npair;                                             \
         if (isshort) {                                                        \
             asm volatile("");   /* exec-masked, not selects */                \
             Qs = fma(q, q, Qs);                                               \
-            ++nshort;                                                         \
+            if (!WAVE_COUNT) ++nshort;                                        \
             if (WF) prodS *= Y;                                               \
         } else {                                                              \
             if (WF) { asm volatile(""); prodL *= fabs(Y); }                   \
@@ -320,9 +355,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         for (int a = 0; a < P; ++a) {
 #pragma unroll
             for (int b = a + 1; b < P; ++b) {
-                double q, Y; bool sh;
-                pair_core<ZCLASS>(m, t[a], aks[a], akc[a], z[a], t[b], z[b], q,
-                                  Y, sh);
+                double q, Y; bool sh; unsigned long long shm;
+                pair_core<ZCLASS>(pc, t[a], aks[a], akc[a], z[a], t[b], z[b], q,
+                                  Y, sh, shm);
+                if (WAVE_COUNT)
+                    ns_wave += __popcll(shm);
                 if (!PAD || (ok[a] && ok[b])) {
                     F[a] += q; F[b] -= q;
                     QMC_TALLY(q, Y, sh);
@@ -337,52 +374,63 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // ---- k = 1 .. G/2: rotate over partner lanes ----
         const int lane = threadIdx.x & 63;
         const int src = lane - gl + ((gl + G - 1) & (G - 1));
-        for (int k = 1; k <= G / 2; ++k) {
-            const bool last = (k == G / 2);
-            const bool count_pair = !last || gl < G / 2;
-            PTab pb[P];
-            double pz[P];
-            bool pok[P];
-#pragma unroll
-            for (int b = 0; b < P; ++b) {
-                int idx = b * 2 * G + gl + G - k;
-                pb[b].s = lS[idx]; pb[b].c = lC[idx];
-                pb[b].su = lSU[idx]; pb[b].cu = lCU[idx];
-                pz[b] = ZCLASS ? lZ[idx] : 0.0;
-                int pl = gl - k; if (pl < 0) pl += G;
-                pok[b] = !PAD || (pl + G * b) < n;
-            }
-#pragma unroll
-            for (int a = 0; a < P; ++a) {
-#pragma unroll
-                for (int b = 0; b < P; ++b) {
-                    double q, Y; bool sh;
-                    pair_core<ZCLASS>(m, t[a], aks[a], akc[a], z[a], pb[b],
-                                      pz[b], q, Y, sh);
-                    if (!PAD || (ok[a] && pok[b])) {
-                        F[a] += q;
-                        if (!last) T[b] -= q;
-                        if (count_pair) { QMC_TALLY(q, Y, sh); }
-                        if (ITH) {
-                            double kk = QMC_PAIR_KIN(q, sh);
-                            Kown[a] += kk;
-                            if (!last) KT[b] += kk;
-                        }
-                    }
-                }
-            }
-            if (!last) {
-#pragma unroll
-                for (int b = 0; b < P; ++b) {
-                    T[b] = __shfl(T[b], src, 64);
-                    if (ITH) KT[b] = __shfl(KT[b], src, 64);
-                }
-            }
-            if (WF && ((k & 7) == 0 || P > 1)) {
-                QMC_FOLD(prodS, expS);
-                QMC_FOLD(prodL, expL);
-            }
+        // One rotation step; LAST is a compile-time flag: the final half step
+        // (k = G/2) visits every pair from both sides, so each side only
+        // updates its own particle and the lower half of the lanes tallies.
+#define QMC_KSTEP(k, LAST)                                                    \
+        {                                                                     \
+            const bool count_pair = !(LAST) || gl < G / 2;                    \
+            PTab pb[P];                                                       \
+            double pz[P];                                                     \
+            bool pok[P];                                                      \
+            _Pragma("unroll")                                                 \
+            for (int b = 0; b < P; ++b) {                                     \
+                int idx = b * 2 * G + gl + G - (k);                           \
+                pb[b].s = lS[idx]; pb[b].c = lC[idx];                         \
+                pb[b].su = lSU[idx]; pb[b].cu = lCU[idx];                     \
+                pz[b] = ZCLASS ? lZ[idx] : 0.0;                               \
+                int pl = gl - (k); if (pl < 0) pl += G;                       \
+                pok[b] = !PAD || (pl + G * b) < n;                            \
+            }                                                                 \
+            _Pragma("unroll")                                                 \
+            for (int a = 0; a < P; ++a) {                                     \
+                _Pragma("unroll")                                             \
+                for (int b = 0; b < P; ++b) {                                 \
+                    double q, Y; bool sh; unsigned long long shm;            \
+                    pair_core<ZCLASS>(pc, t[a], aks[a], akc[a], z[a], pb[b],  \
+                                      pz[b], q, Y, sh, shm);                  \
+                    /* G = 64: the lower half of the lanes is bits 0..31 */   \
+                    if (WAVE_COUNT)                                           \
+                        ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \
+                                                   : shm);                    \
+                    if (!PAD || (ok[a] && pok[b])) {                          \
+                        F[a] += q;                                            \
+                        if (!(LAST)) T[b] -= q;                               \
+                        if (!(LAST) || count_pair) { QMC_TALLY(q, Y, sh); }   \
+                        if (ITH) {                                            \
+                            double kk = QMC_PAIR_KIN(q, sh);                  \
+                            Kown[a] += kk;                                    \
+                            if (!(LAST)) KT[b] += kk;                         \
+                        }                                                     \
+                    }                                                         \
+                }                                                             \
+            }                                                                 \
+            if (!(LAST)) {                                                    \
+                _Pragma("unroll")                                             \
+                for (int b = 0; b < P; ++b) {                                 \
+                    T[b] = __shfl(T[b], src, 64);                             \
+                    if (ITH) KT[b] = __shfl(KT[b], src, 64);                  \
+                }                                                             \
+            }                                                                 \
+            if (WF && (((k) & 7) == 0 || P > 1)) {                            \
+                QMC_FOLD(prodS, expS);                                        \
+                QMC_FOLD(prodL, expL);                                        \
+            }                                                                 \
         }
+        for (int k = 1; k < G / 2; ++k)
+            QMC_KSTEP(k, false)
+        QMC_KSTEP(G / 2, true)
+#undef QMC_KSTEP
         // deliver the travelling sums to their owners (lane gl ^ G/2 holds them)
 #pragma unroll
         for (int b = 0; b < P; ++b) {
@@ -404,20 +452,26 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // sum over unordered pairs of (k2^2 + q^2) [short] and
         // (b_long + q^2 / beta) [long], counted for both partners
         int nlong = npair - nshort;
-        double pk = m.k2sq * (double)nshort + m.b_long * (double)nlong + Qs +
-                    (Qall - Qs) * m.inv_beta;
+        double pk = Qs + (Qall - Qs) * m.inv_beta;
+        if (!WAVE_COUNT)
+            pk += m.k2sq * (double)nshort + m.b_long * (double)nlong;
         e_lane = 2.0 * pk;
 #pragma unroll
         for (int a = 0; a < P; ++a)
             if (ok[a]) e_lane += kin1[a] - F[a] * F[a];
     }
     E = group_sum<G>(e_lane);
+    if (WAVE_COUNT && !ITH && !m.is_ideal) {
+        int nl_wave = n * (n - 1) / 2 - ns_wave;
+        E += 2.0 * (m.k2sq * (double)ns_wave + m.b_long * (double)nl_wave);
+    }
     if (WF) {
         const double LN2 = 0.693147180559945309417;
         double lw = log_pos(prod1 * prodS) + m.beta * log_pos(prodL) +
-                    LN2 * ((double)expS + m.beta * (double)expL) +
-                    (double)nshort * m.log_am;
+                    LN2 * ((double)expS + m.beta * (double)expL);
+        if (!WAVE_COUNT) lw += (double)nshort * m.log_am;
         logwf = group_sum<G>(lw);
+        if (WAVE_COUNT) logwf += (double)ns_wave * m.log_am;
     }
 #undef QMC_FOLD
 #undef QMC_TALLY

@@ -27,6 +27,16 @@ __device__ __forceinline__ double fast_div(double x, double y)
     return fma(rem, r, q);
 }
 
+// Pair-loop quotient: reciprocal estimate + ONE quotient correction (4
+// instructions).  Relative error <= eps_rcp^2 + 2^-53 ~ 8e-16 (eps_rcp = 2^-25).
+__device__ __forceinline__ double pair_div(double x, double y)
+{
+    double r = __builtin_amdgcn_rcp(y);
+    double q = x * r;
+    double rem = fma(-y, q, x);
+    return fma(rem, r, q);
+}
+
 __device__ __forceinline__ double fast_rcp(double y)
 {
     double r = __builtin_amdgcn_rcp(y);
