@@ -1,0 +1,149 @@
+"""Size-independent properties at (or near) the BASELINE.json sizes, where the
+CPU oracle is too slow to be the checker: determinism, independence of a
+chain's trajectory from the ensemble size (counter RNG keyed by chain), exact
+bookkeeping identities of the DMC step, and the symmetries of the model
+(particle permutation, translation by a lattice period)."""
+from math import pi
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def box(n, **kw):
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    d = dict(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+             interaction_strength=2, boson_number=n, supercell_size=n,
+             tbf_contact_cutoff=0.25 * n)
+    d.update(kw)
+    return Spec(**d)
+
+
+@pytest.fixture(scope='module')
+def eng64():
+    from phd_qmclib_amd.engine import ModelEngine
+    e = ModelEngine(box(64).cfc_spec)
+    yield e
+    e.close()
+
+
+def test_vmc_chains_do_not_depend_on_ensemble_size(eng64):
+    """Chain c follows the same trajectory in an ensemble of 2^16 chains and
+    in one of 300 (Philox stream = chain index), and a rerun is bit-identical."""
+    from phd_qmclib_amd.engine import VmcEnsemble
+    rng = np.random.RandomState(1)
+    W = 1 << 16
+    pos = 64 * rng.random_sample((W, 64))
+    big = VmcEnsemble(eng64, W, 0.125, rng_seed=5)
+    big.set_state(pos)
+    a = big.run_block(12)
+    a2 = big.run_block(12)
+    small = VmcEnsemble(eng64, 300, 0.125, rng_seed=5)
+    small.set_state(pos[:300])
+    b = small.run_block(12)
+    b2 = small.run_block(12)
+    for k in ('sum_energy', 'sum_energy2', 'num_accepted'):
+        assert np.array_equal(a[k][:300], b[k]) and \
+            np.array_equal(a2[k][:300], b2[k])
+    again = VmcEnsemble(eng64, W, 0.125, rng_seed=5)
+    again.set_state(pos)
+    c = again.run_block(12)
+    assert np.array_equal(a['sum_energy'], c['sum_energy'])
+    # a rank shard with a chain offset reproduces the tail of the ensemble
+    shard = VmcEnsemble(eng64, 256, 0.125, rng_seed=5, chain0=W - 256)
+    shard.set_state(pos[-256:])
+    d = shard.run_block(12)
+    assert np.array_equal(d['sum_energy'], a['sum_energy'][-256:])
+    # sanity of the physics at scale: E/N of the box and the acceptance
+    e_per = (a2['sum_energy'].sum() / (12 * W)) / 64
+    assert 12 < e_per < 25
+    acc = a2['num_accepted'].sum() / (12 * W)
+    assert 0.3 < acc < 0.8
+    for h in (big, small, again, shard):
+        h.close()
+
+
+def test_dmc_step_identities_at_scale(eng64):
+    """2^16 walkers: unit weights after branching (W_t == n_w), E_t equals the
+    sum of the yielded walkers' energies, the cloning table is non-decreasing
+    and only references parents, population capped, rerun bit-identical."""
+    from phd_qmclib_amd.engine import DmcEnsemble
+    rng = np.random.RandomState(2)
+    target = 1 << 16
+    maxw = target * 512 // 480
+    pos = 64 * rng.random_sample((target, 64))
+
+    def run():
+        d = DmcEnsemble(eng64, 6.25e-4, maxw, target, 0.5, rng_seed=9)
+        d.set_state(pos)
+        ser = d.run_block(9)
+        st = d.get_state()
+        d.close()
+        return ser, st
+    ser, st = run()
+    ser2, st2 = run()
+    assert np.array_equal(ser.energy, ser2.energy)
+    assert np.array_equal(st.cloning_ref, st2.cloning_ref)
+    assert np.array_equal(ser.weight, ser.num_walkers.astype(float))
+    assert np.all(ser.num_walkers <= maxw) and np.all(ser.num_walkers > 0)
+    nw = st.num_walkers
+    assert nw == int(ser.num_walkers[-1])
+    assert np.isclose(st.energy[:nw].sum(), ser.energy[-1], rtol=1e-12)
+    ref = st.cloning_ref[:nw]
+    assert np.all(np.diff(ref) >= 0) and ref[0] >= 0
+    assert ref[-1] < int(ser.num_walkers[-2])
+    # accumulated energy is the running ratio of the series
+    acc = np.cumsum(ser.energy) / np.cumsum(ser.weight)
+    assert np.allclose(acc, ser.accum_energy, rtol=1e-12)
+    # E_ref feedback formula (qmc_base/dmc.py:769-771)
+    ref_e = ser.accum_energy - 0.5 * np.log(ser.weight / target) / 6.25e-4
+    assert np.allclose(ref_e, ser.ref_energy, rtol=1e-12)
+
+
+@pytest.mark.parametrize('n', [64, 128, 512])
+def test_model_symmetries(n):
+    """Bosonic symmetry and lattice periodicity at the large-N shapes:
+    permuting particles permutes the drift and leaves E, log|psi| unchanged;
+    shifting every particle by one lattice period (mod L) changes nothing."""
+    from phd_qmclib_amd.engine import ModelEngine
+    eng = ModelEngine(box(n).cfc_spec)
+    rng = np.random.RandomState(n)
+    pos = n * rng.random_sample((5, n))
+    base = eng.evaluate(pos)
+    perm = rng.permutation(n)
+    p = eng.evaluate(pos[:, perm])
+    tol = 5e-10
+    assert np.allclose(p.energy, base.energy, rtol=tol)
+    assert np.allclose(p.wf_abs_log, base.wf_abs_log, rtol=tol)
+    assert np.allclose(p.drift, base.drift[:, perm], rtol=1e-8, atol=1e-8)
+    sh = eng.evaluate((pos + 1.0) % n)
+    assert np.allclose(sh.energy, base.energy, rtol=tol)
+    assert np.allclose(sh.wf_abs_log, base.wf_abs_log, rtol=tol)
+    assert np.allclose(sh.drift, base.drift, rtol=1e-8, atol=1e-8)
+    assert np.allclose(base.ith_energy.sum(axis=1), base.energy, rtol=1e-12)
+    eng.close()
+
+
+def test_large_n_sampling_runs():
+    """C4 / C5 shapes: DMC at N = 128 and VMC at N = 512 step and stay sane."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
+    eng = ModelEngine(box(128).cfc_spec)
+    rng = np.random.RandomState(3)
+    pos = 128 * rng.random_sample((4096, 128))
+    v = VmcEnsemble(eng, 4096, 0.125, rng_seed=1)
+    v.set_state(pos)
+    v.run_block(30, sums=False)
+    d = DmcEnsemble(eng, 6.25e-4, 4608, 4096, 0.5, rng_seed=1)
+    d.set_state(v.get_state()[0])
+    ser = d.run_block(10)
+    assert np.all(ser.num_walkers > 3000)
+    assert 10 < ser.energy[-1] / ser.weight[-1] / 128 < 30
+    d.close(); v.close(); eng.close()
+    eng = ModelEngine(box(512).cfc_spec)
+    pos = 512 * rng.random_sample((64, 512))
+    v = VmcEnsemble(eng, 64, 0.125, rng_seed=1)
+    v.set_state(pos)
+    out = v.run_block(6)
+    assert np.all(np.isfinite(out['sum_energy']))
+    v.close(); eng.close()
