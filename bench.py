@@ -66,7 +66,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or 'RANK' in os.environ      # launched by torchrun
+    if use_pg:
         dist.init_process_group('nccl', device_id=torch.device('cuda',
                                                                local_rank))
 
@@ -80,7 +81,7 @@ def main():
     eng = ModelEngine(cfc, device=local_rank, stream=stream)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +112,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -121,7 +122,7 @@ def main():
     tot = torch.tensor([res['sum_energy'].sum(), float(res['num_accepted'].sum()),
                         float(W * args.block)], dtype=torch.float64,
                        device='cuda')
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tot)
     tot = tot.cpu().numpy()
 
@@ -243,7 +244,7 @@ def main():
         print(json.dumps(out))
     vmc.close()
     eng.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
