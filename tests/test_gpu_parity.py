@@ -237,3 +237,36 @@ def test_dmc_philox_matches_oracle(engines, oracle, golden_params):
     assert np.array_equal(st.cloning_ref[:st.num_walkers],
                           orc.cloning_ref[:st.num_walkers])
     ens.close()
+
+
+def test_edge_cases_and_errors(engines, golden_params):
+    """Empty batch, single chain, size limits and the error channel of the
+    C-ABI (status code + qmc_last_error -> QmcError)."""
+    from phd_qmclib_amd.engine import (DmcEnsemble, ModelEngine, QmcError,
+                                       VmcEnsemble)
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    eng = engines('box16')
+    out = eng.evaluate(np.zeros((0, 16)))
+    assert out.energy.shape == (0,)
+    with pytest.raises(ValueError):
+        eng.evaluate(np.zeros((3, 15)))
+    big = dict(golden_params['box16']['spec'], boson_number=513,
+               supercell_size=513, tbf_contact_cutoff=100)
+    with pytest.raises(QmcError, match='boson_number'):
+        ModelEngine(Spec(**big).cfc_spec)
+    with pytest.raises(QmcError):
+        VmcEnsemble(eng, 0, 0.1, 1)
+    v = VmcEnsemble(eng, 1, 0.125, rng_seed=1)
+    with pytest.raises(ValueError):
+        v.set_state(np.zeros((2, 16)))
+    v.set_state(8 * np.ones((1, 16)) + np.arange(16) * 0.4)
+    with pytest.raises(QmcError):
+        v.run_block(0)
+    assert v.run_block(3)['num_accepted'][0] >= 1   # the initial yield counts
+    v.close()
+    with pytest.raises(QmcError):
+        DmcEnsemble(eng, -1.0, 16, 8, 0.5, 1)
+    d = DmcEnsemble(eng, 1e-3, 16, 8, 0.5, 1)
+    with pytest.raises(QmcError, match='out of range'):
+        d.set_state(np.zeros((17, 16)))
+    d.close()
