@@ -314,3 +314,80 @@ class DmcEnsemble:
     @property
     def cloning_ref(self):
         return self.bufs['cloning_ref']
+
+
+class DmcEstimators:
+    """numpy restatement of the reference's DMC estimators evaluated on the
+    yielded states of a block:
+
+    * static structure factor parts |rho_k|^2, Re rho_k, Im rho_k, mixed or
+      pure / forward walking (qmc_base/jastrow/dmc.py:363-631; per-block
+      resets qmc_base/dmc.py:897-909),
+    * density histogram, mixed or pure (mrbp_qmc/dmc.py:472-547,
+      qmc_base/jastrow/dmc.py:195-302) -- including the reference's own
+      behaviour that the mixed histogram keeps accumulating in the two
+      alternating per-slot buffers and that the pure one is transported by
+      slot index, not through the cloning table.
+
+    ssf / dens = (num, as_pure_est, pfw_num_time_steps) or None.
+    """
+
+    def __init__(self, supercell_size, num_particles, max_num_walkers,
+                 num_time_steps_block, ssf=None, dens=None):
+        self.L = float(supercell_size)
+        self.n = int(num_particles)
+        self.maxw = int(max_num_walkers)
+        self.nts = int(num_time_steps_block)
+        self.ssf = ssf
+        self.dens = dens
+        if ssf is not None:
+            self.momenta = np.arange(ssf[0]) * 2 * np.pi / self.L
+        self.reset_block()
+
+    def reset_block(self):
+        if self.ssf is not None:
+            m = self.ssf[0]
+            self.iter_ssf = np.zeros((self.nts, m, 3))
+            self.aux_ssf = np.zeros((2, self.maxw, m, 3))
+        if self.dens is not None:
+            b = self.dens[0]
+            self.iter_density = np.zeros((self.nts, b, 1))
+            self.aux_density = np.zeros((2, self.maxw, b, 1))
+
+    def _ssf_parts(self, pos):
+        ph = self.momenta[:, None] * pos[None, :]
+        re, im = np.cos(ph).sum(axis=1), np.sin(ph).sum(axis=1)
+        return np.stack([re * re + im * im, re, im], axis=1)
+
+    def step(self, step_idx, confs, num_walkers, cloning_ref):
+        nw = int(num_walkers)
+        prev_i, act_i = step_idx % 2 - 1, step_idx % 2
+        if self.ssf is not None:
+            m, pure, pfw = self.ssf
+            prev, act = self.aux_ssf[prev_i], self.aux_ssf[act_i]
+            for s in range(nw):
+                if not pure:
+                    act[s] = self._ssf_parts(confs[s, 0])
+                elif step_idx >= pfw:
+                    act[s] = prev[cloning_ref[s]]
+                else:
+                    act[s] = self._ssf_parts(confs[s, 0]) + prev[cloning_ref[s]]
+            div = 1 if not pure else (step_idx + 1 if step_idx < pfw else pfw)
+            self.iter_ssf[step_idx] = act[:nw].sum(axis=0)
+            if pure:
+                self.iter_ssf[step_idx] /= div
+        if self.dens is not None:
+            b, pure, pfw = self.dens
+            prev, act = self.aux_density[prev_i], self.aux_density[act_i]
+            bin_size = self.L / b
+            if pure:
+                act[:] = prev
+            for s in range(nw):
+                if pure and step_idx >= pfw:
+                    continue
+                for z in confs[s, 0]:
+                    act[s, int(z // bin_size), 0] += 1
+            div = 1 if not pure else (step_idx + 1 if step_idx < pfw else pfw)
+            self.iter_density[step_idx] = act[:nw].sum(axis=0)
+            if pure:
+                self.iter_density[step_idx] /= div

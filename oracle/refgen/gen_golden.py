@@ -369,7 +369,65 @@ def gen_stats():
     np.savez_compressed(os.path.join(OUT, 'stats.npz'), **out)
 
 
-ALL = dict(params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
+def gen_dmc_est():
+    """DMC estimators: S(k) and density, mixed and pure
+    (forward walking), through `Sampling.blocks` with a burned block so the
+    gating and the per-block resets are exercised; RNG streams recorded so the
+    runs can be replayed."""
+    out = {}
+    spec = mrbp_qmc.Spec(**SPECS['box8'])
+    dt, target, maxw, kappa, nts, nblocks, burn = 1e-3, 20, 26, 0.5, 6, 3, 1
+    cases = [('ssf_mixed', dict(ssf=(8, False, None))),
+             ('ssf_pure', dict(ssf=(8, True, 4))),
+             ('ssf_pure_full', dict(ssf=(5, True, None))),
+             ('dens_mixed', dict(dens=(12, False, 99999999))),
+             ('dens_pure', dict(dens=(12, True, 4))),
+             ('both', dict(ssf=(8, True, None), dens=(16, True, 99999999)))]
+    for tag, cfg in cases:
+        np.random.seed(2718)
+        ini_set = np.array([spec.init_get_sys_conf() for _ in range(18)])
+        ssf_spec = dens_spec = None
+        if 'ssf' in cfg:
+            nm, pure, pfw = cfg['ssf']
+            ssf_spec = mrbp_qmc.dmc.SSFEstSpec(nm, pure, pfw)
+        if 'dens' in cfg:
+            nb, pure, pfw = cfg['dens']
+            dens_spec = mrbp_qmc.dmc.DensityEstSpec(nb, pure, pfw)
+        smp = mrbp_qmc.dmc.Sampling(spec, dt, max_num_walkers=maxw,
+                                    target_num_walkers=target,
+                                    num_walkers_control_factor=kappa,
+                                    rng_seed=3, density_est_spec=dens_spec,
+                                    ssf_est_spec=ssf_spec, jit_parallel=False)
+        st0 = smp.build_state(ini_set)
+        ssf_blocks, dens_blocks, nws, nus, nns = [], [], [], [], []
+        with harness.RNGTape() as tape:
+            for blk in islice(smp.blocks(st0, nts, burn), nblocks):
+                ssf_blocks.append(np.array(blk.iter_ssf, copy=True))
+                dens_blocks.append(np.array(blk.iter_density, copy=True))
+                nws.append(blk.iter_props.num_walkers.copy())
+        out[tag + '/ini_pos'] = ini_set[:, 0, :].copy()
+        out[tag + '/cfg'] = np.array([dt, target, maxw, kappa, nts, nblocks,
+                                      burn])
+        out[tag + '/uniform'] = np.array(tape.uniform)
+        out[tag + '/normal'] = np.array(tape.normal)
+        out[tag + '/num_walkers'] = np.array(nws).astype(np.int64)
+        if ssf_spec is not None:
+            out[tag + '/ssf_cfg'] = np.array([ssf_spec.num_modes,
+                                              int(ssf_spec.as_pure_est),
+                                              ssf_spec.pfw_num_time_steps])
+            out[tag + '/iter_ssf'] = np.array(ssf_blocks)
+        if dens_spec is not None:
+            out[tag + '/dens_cfg'] = np.array([dens_spec.num_bins,
+                                               int(dens_spec.as_pure_est),
+                                               dens_spec.pfw_num_time_steps])
+            out[tag + '/iter_density'] = np.array(dens_blocks)
+        print('dmc_est', tag, np.array(nws)[:, -1],
+              None if ssf_spec is None else np.array(ssf_blocks)[1, -1, 1],
+              None if dens_spec is None else np.array(dens_blocks)[1, -1, :3, 0])
+    np.savez_compressed(os.path.join(OUT, 'dmc_est.npz'), **out)
+
+
+ALL = dict(dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
            dmc_tape=gen_dmc_tape, reblock=gen_reblock, stats=gen_stats)
 
 if __name__ == '__main__':
