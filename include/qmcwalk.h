@@ -85,6 +85,19 @@ typedef struct {
     int32_t reserved;
 } qmc_dmc_params;
 
+/* Estimator specs of a DMC sampling (mrbp_qmc/dmc.py:103-140, 187-225):
+ * static structure factor over num_modes momenta k_m = 2 pi m / L and density
+ * histogram over num_bins bins, each mixed or pure (forward walking over
+ * pfw_num_time_steps).  0 modes / bins disables an estimator. */
+typedef struct {
+    int32_t num_modes;
+    int32_t ssf_pure;
+    int64_t ssf_pfw;
+    int32_t num_bins;
+    int32_t dens_pure;
+    int64_t dens_pfw;
+} qmc_dmc_est_params;
+
 const char *qmc_last_error(void);
 int qmc_abi_version(void);
 int qmc_device_count(int *count);
@@ -161,6 +174,17 @@ int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw, const double *confs,
 int qmc_dmc_run_block(qmc_dmc *d, int64_t nsteps, double *energy,
                       double *weight, uint64_t *num_walkers,
                       double *ref_energy, double *accum_energy);
+/* Estimators of core_funcs.blocks (qmc_base/dmc.py:897-940;
+ * qmc_base/jastrow/dmc.py:195-302, 363-631; mrbp_qmc/dmc.py:472-547).
+ * run_block_est = run_block + per-step iter_ssf[nsteps][num_modes][3] /
+ * iter_density[nsteps][num_bins] (host, may be NULL); the per-walker
+ * forward-walking buffers are reset at the start of every block and the
+ * estimators are skipped when eval_estimators == 0 (burn-in blocks). */
+int qmc_dmc_set_estimators(qmc_dmc *d, const qmc_dmc_est_params *p);
+int qmc_dmc_run_block_est(qmc_dmc *d, int64_t nsteps, int eval_estimators,
+                          double *energy, double *weight, uint64_t *num_walkers,
+                          double *ref_energy, double *accum_energy,
+                          double *iter_ssf, double *iter_density);
 /* The yielded ("actual") State after the last step (qmc_base/dmc.py:773-780):
  * confs[maxw][2][N], energy/weight[maxw], mask[maxw], cloning_ref[maxw];
  * scalars[5] = energy, weight, ref_energy, accum_energy, num_walkers. */

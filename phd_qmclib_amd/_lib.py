@@ -54,6 +54,12 @@ class DmcParams(C.Structure):
                 ('external_reduce', C.c_int32), ('reserved', C.c_int32)]
 
 
+class DmcEstParams(C.Structure):
+    _fields_ = [('num_modes', C.c_int32), ('ssf_pure', C.c_int32),
+                ('ssf_pfw', C.c_int64), ('num_bins', C.c_int32),
+                ('dens_pure', C.c_int32), ('dens_pfw', C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/qmcwalk.h declares
 SIGNATURES = {
     'qmc_last_error': (C.c_char_p, []),
@@ -83,6 +89,9 @@ SIGNATURES = {
                                          C.c_double]),
     'qmc_dmc_run_block': (C.c_int, [_vp, C.c_int64, _dp, _dp, _u64p, _dp,
                                     _dp]),
+    'qmc_dmc_set_estimators': (C.c_int, [_vp, C.POINTER(DmcEstParams)]),
+    'qmc_dmc_run_block_est': (C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp,
+                                        _u64p, _dp, _dp, _dp, _dp]),
     'qmc_dmc_get_state': (C.c_int, [_vp, _dp, _dp, _dp, _u8p, _i64p, _dp]),
     'qmc_dmc_step_local': (C.c_int, [_vp, _vp]),
     'qmc_dmc_step_finish': (C.c_int, [_vp, _vp]),

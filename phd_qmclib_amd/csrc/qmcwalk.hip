@@ -584,6 +584,170 @@ __global__ void dmc_finish_kernel(FinishArgs a)
     c->step += 1;
 }
 
+// ---- DMC estimators ------------------------------
+// Evaluated on the yielded population of a step: walker s carries the
+// configuration of its parent, parents[ref[s]] (qmc_base/dmc.py:773-780).
+struct EstArgs {
+    const double *ppos;       // parent positions [maxw][N]
+    const long long *ref;     // cloning table
+    const DmcCtl *ctl;
+    const double *aux_prev;   // [maxw][K][C] per-walker parts one step ago
+    double *aux_act;          // [maxw][K][C] per-walker parts of this step
+    double *partial;          // [nblocks][K][C] block partial sums
+    long long maxw;
+    long long step_idx;       // index of the step inside the block
+    long long pfw;            // forward-walking length
+    int n;                    // particles
+    int K;                    // modes or bins
+    int pure;
+    double scale;             // S(k): 4 / L (angle k_m z = (pi/2) * m * scale * z)
+                              // density: bin size L / num_bins
+};
+
+static constexpr int EST_BLOCKS = 512;
+static constexpr int EST_MAXK = 256;        // modes / bins supported per call
+static constexpr int EST_CH = EST_MAXK / 64;
+
+// Static structure factor parts of every yielded walker, lane = mode:
+// rho_k = sum_i exp(i k z_i), parts (|rho_k|^2, Re, Im); mixed estimator or
+// forward-walking transport through the cloning table
+// (qmc_base/jastrow/dmc.py:363-461, 483-566).
+__global__ void __launch_bounds__(BLOCK) dmc_ssf_kernel(EstArgs a)
+{
+    extern __shared__ double smem[];
+    __shared__ double red[BLOCK / 64][EST_MAXK][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *zs = smem + (size_t)wave * a.n;
+    const long long nw = a.ctl->nw;
+    const long long wstride = (long long)gridDim.x * (BLOCK / 64);
+    double acc[EST_CH][3];
+#pragma unroll
+    for (int c = 0; c < EST_CH; ++c) acc[c][0] = acc[c][1] = acc[c][2] = 0.0;
+    const bool accumulate = !a.pure || a.step_idx < a.pfw;
+    for (long long s = (long long)blockIdx.x * (BLOCK / 64) + wave; s < nw;
+         s += wstride) {
+        const long long par = a.ref[s];
+        if (accumulate) {
+            for (int i = lane; i < a.n; i += 64) zs[i] = a.ppos[par * a.n + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int c = 0; c < EST_CH; ++c) {
+            const int mo = c * 64 + lane;
+            if (c * 64 >= a.K) break;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            if (mo < a.K) {
+                if (accumulate) {
+                    double re = 0.0, im = 0.0;
+                    const double f = (double)mo * a.scale;
+                    for (int i = 0; i < a.n; ++i) {
+                        double sn, cs;
+                        sincos_halfpi(f * zs[i], sn, cs);
+                        re += cs;
+                        im += sn;
+                    }
+                    v0 = fma(re, re, im * im); v1 = re; v2 = im;
+                }
+                if (a.pure) {
+                    const double *pp = a.aux_prev + ((size_t)par * a.K + mo) * 3;
+                    v0 += pp[0]; v1 += pp[1]; v2 += pp[2];
+                    double *ap = a.aux_act + ((size_t)s * a.K + mo) * 3;
+                    ap[0] = v0; ap[1] = v1; ap[2] = v2;
+                }
+            }
+            acc[c][0] += v0; acc[c][1] += v1; acc[c][2] += v2;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // fixed-order block reduction: waves 0..3, then the reduce kernel sums the
+    // blocks in index order
+#pragma unroll
+    for (int c = 0; c < EST_CH; ++c) {
+        const int mo = c * 64 + lane;
+        red[wave][mo][0] = acc[c][0];
+        red[wave][mo][1] = acc[c][1];
+        red[wave][mo][2] = acc[c][2];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < a.K * 3; idx += BLOCK) {
+        const int mo = idx / 3, cpt = idx % 3;
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += red[w][mo][cpt];
+        a.partial[((size_t)blockIdx.x * a.K + mo) * 3 + cpt] = t;
+    }
+}
+
+// Density histogram of every slot, lane = bin.  Reproduces the reference:
+// the mixed estimator keeps adding into the slot's alternating buffer, the
+// pure one copies the previous buffer slot by slot (no cloning table) and
+// adds the current histogram while step < pfw (mrbp_qmc/dmc.py:472-547,
+// qmc_base/jastrow/dmc.py:238-302).
+__global__ void __launch_bounds__(BLOCK) dmc_density_kernel(EstArgs a)
+{
+    __shared__ int hist[BLOCK / 64][EST_MAXK];
+    __shared__ double red[BLOCK / 64][EST_MAXK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long nw = a.ctl->nw;
+    const long long wstride = (long long)gridDim.x * (BLOCK / 64);
+    double acc[EST_CH];
+#pragma unroll
+    for (int c = 0; c < EST_CH; ++c) acc[c] = 0.0;
+    const bool count_now = !a.pure || a.step_idx < a.pfw;
+    for (long long s = (long long)blockIdx.x * (BLOCK / 64) + wave; s < a.maxw;
+         s += wstride) {
+        const bool live = s < nw;
+        if (!live && !a.pure) break;      // mixed: dead slots keep their data
+        for (int b = lane; b < a.K; b += 64) hist[wave][b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (live && count_now) {
+            const long long par = a.ref[s];
+            for (int i = lane; i < a.n; i += 64) {
+                int b = (int)floor(a.ppos[par * a.n + i] / a.scale);
+                b = b < 0 ? 0 : (b >= a.K ? a.K - 1 : b);
+                atomicAdd(&hist[wave][b], 1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < EST_CH; ++c) {
+            const int b = c * 64 + lane;
+            if (c * 64 >= a.K) break;
+            if (b < a.K) {
+                const size_t o = (size_t)s * a.K + b;
+                double v = (a.pure ? a.aux_prev[o] : a.aux_act[o]) +
+                           (double)hist[wave][b];
+                a.aux_act[o] = v;
+                if (live) acc[c] += v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int c = 0; c < EST_CH; ++c) red[wave][c * 64 + lane] = acc[c];
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.K; b += BLOCK) {
+        double t = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += red[w][b];
+        a.partial[(size_t)blockIdx.x * a.K + b] = t;
+    }
+}
+
+// iter[step][k][c] = (sum over blocks, in order) / divisor
+__global__ void est_reduce_kernel(const double *partial, int nblocks, int KC,
+                                  double divisor, double *out)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KC) return;
+    double t = 0.0;
+    for (int b = 0; b < nblocks; ++b) t += partial[(size_t)b * KC + idx];
+    out[idx] = t / divisor;
+}
+
+
 // Gather the yielded ("actual") configurations: confs[s] = parents[ref[s]].
 __global__ void dmc_gather_state_kernel(const double *ppos,
                                         const double *pdrift,
@@ -1116,6 +1280,14 @@ struct qmc_dmc {
     long long tape_step = 0;
     bool stepped = false;        // a step has run since the last set_state
     double global_target = 0.0;
+    // estimators (f1)
+    qmc_dmc_est_params est;
+    bool have_est = false;
+    double *ssf_aux[2] = { nullptr, nullptr };   // [maxw][M][3]
+    double *dens_aux[2] = { nullptr, nullptr };  // [maxw][B]
+    double *est_partial = nullptr;               // [EST_BLOCKS][max(3M, B)]
+    double *iter_ssf = nullptr, *iter_dens = nullptr;
+    long long iter_cap = 0;
 };
 
 static int dmc_reserve_series(qmc_dmc *d, long long nsteps)
@@ -1179,6 +1351,13 @@ extern "C" void qmc_dmc_destroy(qmc_dmc *d)
                     hipFree(d->ser_acc); hipFree(d->ser_nw); }
     if (d->u_tape) hipFree(d->u_tape);
     if (d->g_tape) hipFree(d->g_tape);
+    for (int k = 0; k < 2; ++k) {
+        if (d->ssf_aux[k]) hipFree(d->ssf_aux[k]);
+        if (d->dens_aux[k]) hipFree(d->dens_aux[k]);
+    }
+    if (d->est_partial) hipFree(d->est_partial);
+    if (d->iter_ssf) hipFree(d->iter_ssf);
+    if (d->iter_dens) hipFree(d->iter_dens);
     delete d;
 }
 
@@ -1420,6 +1599,136 @@ extern "C" int qmc_dmc_run_block(qmc_dmc *d, int64_t nsteps, double *energy,
         return qmc_dmc_read_series(d, nsteps, energy, weight, num_walkers,
                                    ref_energy, accum_energy);
     return 0;
+}
+
+extern "C" int qmc_dmc_set_estimators(qmc_dmc *d, const qmc_dmc_est_params *p)
+{
+    if (!d || !p) return fail("qmc_dmc_set_estimators: null argument");
+    if (p->num_modes < 0 || p->num_modes > EST_MAXK || p->num_bins < 0 ||
+        p->num_bins > EST_MAXK)
+        return fail("qmc_dmc_set_estimators: num_modes / num_bins must be in "
+                    "[0, 256]");
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    for (int k = 0; k < 2; ++k) {
+        if (d->ssf_aux[k]) { hipFree(d->ssf_aux[k]); d->ssf_aux[k] = nullptr; }
+        if (d->dens_aux[k]) { hipFree(d->dens_aux[k]); d->dens_aux[k] = nullptr; }
+    }
+    if (d->est_partial) { hipFree(d->est_partial); d->est_partial = nullptr; }
+    d->est = *p;
+    d->have_est = p->num_modes > 0 || p->num_bins > 0;
+    const size_t W = (size_t)d->maxw;
+    if (p->num_modes > 0)
+        for (int k = 0; k < 2; ++k)
+            if (dev_alloc(&d->ssf_aux[k], W * (size_t)p->num_modes * 3)) return 1;
+    if (p->num_bins > 0)
+        for (int k = 0; k < 2; ++k)
+            if (dev_alloc(&d->dens_aux[k], W * (size_t)p->num_bins)) return 1;
+    size_t kc = (size_t)(p->num_modes * 3 > p->num_bins ? p->num_modes * 3
+                                                        : p->num_bins);
+    if (d->have_est && dev_alloc(&d->est_partial, EST_BLOCKS * kc)) return 1;
+    return 0;
+}
+
+// Evaluate the estimators on the population yielded by the step that has just
+// been finished (its parents are the buffer that is not `cur`).
+static int dmc_enqueue_estimators(qmc_dmc *d, long long step_idx)
+{
+    qmc_engine *e = d->eng;
+    const int par = 1 - d->cur;
+    const int act = (int)(step_idx % 2), prev = 1 - act;
+    EstArgs a;
+    a.ppos = d->pos[par]; a.ref = d->ref; a.ctl = d->ctl;
+    a.maxw = d->maxw; a.step_idx = step_idx; a.n = e->dm.n;
+    a.partial = d->est_partial;
+    if (d->est.num_modes > 0) {
+        const int M = d->est.num_modes;
+        a.aux_prev = d->ssf_aux[prev]; a.aux_act = d->ssf_aux[act];
+        a.K = M; a.pure = d->est.ssf_pure; a.pfw = d->est.ssf_pfw;
+        a.scale = 4.0 / e->dm.L;
+        const size_t lds = (size_t)(BLOCK / 64) * a.n * sizeof(double);
+        hipLaunchKernelGGL(dmc_ssf_kernel, dim3(EST_BLOCKS), dim3(BLOCK), lds,
+                           e->stream, a);
+        double div = 1.0;
+        if (a.pure) div = step_idx < a.pfw ? (double)(step_idx + 1)
+                                           : (double)a.pfw;
+        hipLaunchKernelGGL(est_reduce_kernel, dim3((M * 3 + 255) / 256),
+                           dim3(256), 0, e->stream, d->est_partial, EST_BLOCKS,
+                           M * 3, div, d->iter_ssf + (size_t)step_idx * M * 3);
+    }
+    if (d->est.num_bins > 0) {
+        const int B = d->est.num_bins;
+        a.aux_prev = d->dens_aux[prev]; a.aux_act = d->dens_aux[act];
+        a.K = B; a.pure = d->est.dens_pure; a.pfw = d->est.dens_pfw;
+        a.scale = e->dm.L / (double)B;      // bin size
+        hipLaunchKernelGGL(dmc_density_kernel, dim3(EST_BLOCKS), dim3(BLOCK), 0,
+                           e->stream, a);
+        double div = 1.0;
+        if (a.pure) div = step_idx < a.pfw ? (double)(step_idx + 1)
+                                           : (double)a.pfw;
+        hipLaunchKernelGGL(est_reduce_kernel, dim3((B + 255) / 256), dim3(256),
+                           0, e->stream, d->est_partial, EST_BLOCKS, B, div,
+                           d->iter_dens + (size_t)step_idx * B);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int qmc_dmc_run_block_est(qmc_dmc *d, int64_t nsteps,
+                                     int eval_estimators, double *energy,
+                                     double *weight, uint64_t *num_walkers,
+                                     double *ref_energy, double *accum_energy,
+                                     double *iter_ssf, double *iter_density)
+{
+    if (!d) return fail("qmc_dmc_run_block_est: null argument");
+    if (nsteps <= 0) return fail("qmc_dmc_run_block_est: nsteps must be >= 1");
+    if (d->p.external_reduce)
+        return fail("qmc_dmc_run_block_est: not available with external_reduce");
+    if (!d->have_est)
+        return qmc_dmc_run_block(d, nsteps, energy, weight, num_walkers,
+                                 ref_energy, accum_energy);
+    qmc_engine *e = d->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    if (dmc_reserve_series(d, nsteps)) return 1;
+    const size_t M3 = (size_t)d->est.num_modes * 3, B = (size_t)d->est.num_bins;
+    const size_t W = (size_t)d->maxw;
+    if (nsteps > d->iter_cap) {
+        if (d->iter_ssf) { hipFree(d->iter_ssf); d->iter_ssf = nullptr; }
+        if (d->iter_dens) { hipFree(d->iter_dens); d->iter_dens = nullptr; }
+        if (dev_alloc(&d->iter_ssf, (size_t)nsteps * (M3 ? M3 : 1)) ||
+            dev_alloc(&d->iter_dens, (size_t)nsteps * (B ? B : 1)))
+            return 1;
+        d->iter_cap = nsteps;
+    }
+    // per-block resets (qmc_base/dmc.py:897-909)
+    HIP_TRY(hipMemsetAsync(d->iter_ssf, 0, (size_t)nsteps * (M3 ? M3 : 1) * 8,
+                           e->stream));
+    HIP_TRY(hipMemsetAsync(d->iter_dens, 0, (size_t)nsteps * (B ? B : 1) * 8,
+                           e->stream));
+    for (int k = 0; k < 2; ++k) {
+        if (M3) HIP_TRY(hipMemsetAsync(d->ssf_aux[k], 0, W * M3 * 8, e->stream));
+        if (B) HIP_TRY(hipMemsetAsync(d->dens_aux[k], 0, W * B * 8, e->stream));
+    }
+    d->ser_len = 0;
+    for (long long t = 0; t < nsteps; ++t) {
+        int rc = dmc_enqueue_local(d, nullptr);
+        if (rc) return rc;
+        rc = dmc_enqueue_finish(d, nullptr, t);
+        if (rc) return rc;
+        d->ser_len = t + 1;
+        if (eval_estimators) {
+            rc = dmc_enqueue_estimators(d, t);
+            if (rc) return rc;
+        }
+    }
+    if (iter_ssf && M3)
+        HIP_TRY(hipMemcpyAsync(iter_ssf, d->iter_ssf, (size_t)nsteps * M3 * 8,
+                               hipMemcpyDeviceToHost, e->stream));
+    if (iter_density && B)
+        HIP_TRY(hipMemcpyAsync(iter_density, d->iter_dens, (size_t)nsteps * B * 8,
+                               hipMemcpyDeviceToHost, e->stream));
+    return qmc_dmc_read_series(d, nsteps, energy, weight, num_walkers,
+                               ref_energy, accum_energy);
 }
 
 extern "C" int qmc_dmc_step_local(qmc_dmc *d, double *partial_dev)

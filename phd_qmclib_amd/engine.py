@@ -8,7 +8,8 @@ import typing as t
 import numpy as np
 
 from . import _lib
-from ._lib import (DmcParams, ModelParams, QmcError, VmcParams, check, ptr,
+from ._lib import (DmcEstParams, DmcParams, ModelParams, QmcError, VmcParams,
+                   check, ptr,
                    _i64p, _u64p, _u8p)
 
 __all__ = ['ModelEngine', 'VmcEnsemble', 'DmcEnsemble', 'EvalResult',
@@ -303,6 +304,28 @@ class DmcEnsemble:
         check(self._lib.qmc_dmc_run_block(self._h, int(nsteps), ptr(e), ptr(w),
                                           ptr(nw, _u64p), ptr(r), ptr(a)))
         return DmcSeries(e, w, nw, r, a)
+
+    def set_estimators(self, num_modes=0, ssf_pure=False, ssf_pfw=1,
+                       num_bins=0, dens_pure=False, dens_pfw=1):
+        """Enable the S(k) / density estimators (0 disables one)."""
+        self.num_modes, self.num_bins = int(num_modes), int(num_bins)
+        p = DmcEstParams(self.num_modes, int(bool(ssf_pure)), int(ssf_pfw),
+                         self.num_bins, int(bool(dens_pure)), int(dens_pfw))
+        check(self._lib.qmc_dmc_set_estimators(self._h, C.byref(p)))
+
+    def run_block_est(self, nsteps: int, eval_estimators: bool = True):
+        """-> (DmcSeries, iter_ssf[nsteps, M, 3] or None,
+        iter_density[nsteps, B, 1] or None)."""
+        M, B = getattr(self, 'num_modes', 0), getattr(self, 'num_bins', 0)
+        e, w = np.zeros(nsteps), np.zeros(nsteps)
+        nw = np.zeros(nsteps, dtype=np.uint64)
+        r, a = np.zeros(nsteps), np.zeros(nsteps)
+        ssf = np.zeros((nsteps, M, 3)) if M else None
+        dens = np.zeros((nsteps, B, 1)) if B else None
+        check(self._lib.qmc_dmc_run_block_est(
+            self._h, int(nsteps), int(bool(eval_estimators)), ptr(e), ptr(w),
+            ptr(nw, _u64p), ptr(r), ptr(a), ptr(ssf), ptr(dens)))
+        return DmcSeries(e, w, nw, r, a), ssf, dens
 
     def read_series(self, nsteps: int) -> DmcSeries:
         e, w = np.zeros(nsteps), np.zeros(nsteps)

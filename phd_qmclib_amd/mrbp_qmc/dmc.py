@@ -9,8 +9,9 @@ round trip and only the per-step series come back.
 `jit_parallel` / `jit_fastmath` are accepted for drop-in compatibility and
 ignored (there is no numba here).  `fix_stale_energy` is an extension: False
 reproduces the reference's branching weight, True uses the
-parent's energy.  The density / S(k) estimators are not implemented yet
-(SURVEY.md 8f row f1): passing their specs raises NotImplementedError.
+parent's energy.  The density / S(k) estimators (mixed and pure /
+forward-walking) run on the device after every kept
+time step and reproduce the reference's semantics, per-block resets included.
 """
 import typing as t
 from math import pi, sqrt
@@ -107,10 +108,6 @@ class Sampling:
                                int(utils.get_random_rng_seed()))
         if self.num_walkers_control_factor is None:
             object.__setattr__(self, 'num_walkers_control_factor', 1.25e-1)
-        if self.density_est_spec is not None or self.ssf_est_spec is not None:
-            raise NotImplementedError(
-                'density / structure-factor estimators are not part of the '
-                'accelerated path yet (SURVEY.md 8f, row f1)')
 
     # -- parameters (mrbp_qmc/dmc.py:172-236) ---------------------------------
     @property
@@ -121,11 +118,28 @@ class Sampling:
 
     @property
     def density_params(self) -> DensityParams:
-        return DensityParams(1, False, 1, True)
+        """mrbp_qmc/dmc.py:187-204."""
+        d = self.density_est_spec
+        if d is None:
+            return DensityParams(1, False, 1, True)
+        return DensityParams(d.num_bins, d.as_pure_est, d.pfw_num_time_steps,
+                             False)
 
     @property
     def ssf_params(self) -> SSFParams:
-        return SSFParams(1, False, 1, True)
+        """mrbp_qmc/dmc.py:206-225."""
+        f = self.ssf_est_spec
+        if f is None:
+            return SSFParams(1, False, 1, True)
+        return SSFParams(f.num_modes, f.as_pure_est, f.pfw_num_time_steps,
+                         False)
+
+    @property
+    def density_bins_edges(self) -> np.ndarray:
+        if self.density_est_spec is None:
+            raise TypeError('the density spec has no been specified')
+        return np.linspace(0, self.model_spec.supercell_size,
+                           self.density_est_spec.num_bins + 1)
 
     @property
     def cfc_spec(self) -> CFCSpec:
@@ -232,14 +246,32 @@ class Sampling:
         estimators in the reference; the propagation is identical."""
         nts = int(num_time_steps_block)
         eng, ens = self._start(ini_state)
+        dp, sp = self.density_params, self.ssf_params
+        with_est = not (dp.assume_none and sp.assume_none)
+        if with_est:
+            ens.set_estimators(
+                0 if sp.assume_none else sp.num_modes, sp.as_pure_est,
+                sp.pfw_num_time_steps,
+                0 if dp.assume_none else dp.num_bins, dp.as_pure_est,
+                dp.pfw_num_time_steps)
+        block_idx = 0
         try:
             while True:
-                ser = ens.run_block(nts)
+                iter_ssf = iter_density = None
+                if with_est:
+                    # estimators only once the burn-in blocks are over
+                    # (qmc_base/dmc.py:916, 928)
+                    ser, iter_ssf, iter_density = ens.run_block_est(
+                        nts, block_idx >= burn_in_blocks)
+                else:
+                    ser = ens.run_block(nts)
                 props = dmc_base.PropsData(ser.energy, ser.weight,
                                            ser.num_walkers, ser.ref_energy,
                                            ser.accum_energy)
                 last = self._to_state(ens.get_state())
-                yield dmc_base.SamplingBlock(props, None, None, last)
+                yield dmc_base.SamplingBlock(props, iter_density, iter_ssf,
+                                             last)
+                block_idx += 1
         finally:
             ens.close()
             eng.close()

@@ -270,3 +270,49 @@ def test_edge_cases_and_errors(engines, golden_params):
     with pytest.raises(QmcError, match='out of range'):
         d.set_state(np.zeros((17, 16)))
     d.close()
+
+
+@pytest.mark.parametrize('tag', ['ssf_mixed', 'ssf_pure', 'ssf_pure_full',
+                                 'dens_mixed', 'dens_pure', 'both'])
+def test_dmc_estimators_tape_replay(engines, oracle, golden_params, tag):
+    """S(k) and density estimators (mixed / pure) of the device against the
+    reference's `Sampling.blocks` output on a replayed run, burned block and
+    per-block resets included (tests/golden/dmc_est.npz)."""
+    import os
+    from phd_qmclib_amd.engine import DmcEnsemble
+    from .conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'dmc_est.npz'), allow_pickle=False)
+    eng = engines('box8')
+    dt, target, maxw, kappa, nts, nblocks, burn = g[tag + '/cfg']
+    target, maxw, nts, nblocks, burn = map(int, (target, maxw, nts, nblocks,
+                                                 burn))
+    # per-step draw counts from the (pinned) oracle replay
+    m = oracle_model(oracle, golden_params, 'box8')
+    orc = oracle.DmcEnsemble(m, g[tag + '/ini_pos'], dt, maxw, target, kappa)
+    u, gg = g[tag + '/uniform'], g[tag + '/normal']
+    u_off, g_off, uo, go = [], [], 0, 0
+    for _ in range(nts * nblocks):
+        u_off.append(uo); g_off.append(go)
+        o = orc.step(np.r_[u[uo:], np.zeros(64)], gg[go:])
+        uo += o.n_uniform; go += o.n_normal
+    ens = DmcEnsemble(eng, dt, maxw, target, kappa, rng_seed=3)
+    ens.set_state(g[tag + '/ini_pos'][-target:])
+    ens.set_tape(u, gg, u_off, g_off)
+    kw = {}
+    if tag + '/ssf_cfg' in g:
+        c = g[tag + '/ssf_cfg']
+        kw.update(num_modes=int(c[0]), ssf_pure=bool(c[1]), ssf_pfw=int(c[2]))
+    if tag + '/dens_cfg' in g:
+        c = g[tag + '/dens_cfg']
+        kw.update(num_bins=int(c[0]), dens_pure=bool(c[1]), dens_pfw=int(c[2]))
+    ens.set_estimators(**kw)
+    for b in range(nblocks):
+        ser, ssf, dens = ens.run_block_est(nts, b >= burn)
+        assert np.array_equal(ser.num_walkers.astype(np.int64),
+                              g[tag + '/num_walkers'][b])
+        if ssf is not None:
+            ref = g[tag + '/iter_ssf'][b]
+            assert np.allclose(ssf, ref, rtol=1e-10, atol=1e-9), (b, worst(ssf, ref))
+        if dens is not None:
+            assert np.array_equal(dens, g[tag + '/iter_density'][b]), b
+    ens.close()
