@@ -315,6 +315,40 @@ def gen_reblock():
             out[tag + '/vmc_mean_error'] = np.float64(vb.mean_error)
         print('reblock', tag, out[tag + '/opt_block_size'],
               out[tag + '/dmc_mean'], out[tag + '/dmc_mean_error'])
+    # 2-D (set) reblocking: the containers of S(k) / density block totals
+    import warnings
+    x2 = np.zeros((256, 5))
+    e2 = rng.normal(size=(256, 5))
+    for k in range(1, 256):
+        x2[k] = 0.5 * x2[k - 1] + e2[k]
+    x2 += np.arange(1, 6) * 3.0
+    w2 = 480.0 + 10 * rng.normal(size=256)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        st = rb.OTFSet.from_non_obj_data(x2)
+        out['set/x'] = x2
+        out['set/w'] = w2
+        out['set/block_sizes'] = np.array(st.block_sizes)
+        out['set/num_blocks'] = np.array(st.num_blocks)
+        out['set/means'] = np.array(st.means)
+        out['set/vars'] = np.array(st.vars)
+        out['set/iac_times'] = np.array(st.iac_times)
+        out['set/opt_block_size'] = np.array(st.opt_block_size)
+        out['set/opt_iac_time'] = np.array(st.opt_iac_time)
+        out['set/eff_size'] = np.array(st.eff_size)
+        out['set/mean_eff_error'] = np.array(st.mean_eff_error)
+        pb = dmc_data.SSFPartBlocks(x2 * w2[:, None], w2[:, None])
+        out['set/part_mean'] = np.array(pb.mean)
+        out['set/part_mean_error'] = np.array(pb.mean_error)
+        ssf3 = np.stack([x2 ** 2 + 40, x2, 0.1 * x2], axis=2) * w2[:, None, None]
+        class _P:  # minimal PropsData stand-in (block weight totals)
+            weight = w2
+        sb = dmc_data.SSFBlocks.from_data(4, ssf3, _P, reduce_data=False,
+                                          as_pure_est=False)
+        out['set/ssf3'] = ssf3
+        out['set/ssf_mean'] = np.array(sb.mean)
+        out['set/ssf_mean_error'] = np.array(sb.mean_error)
+    print('reblock set', out['set/opt_block_size'], out['set/part_mean'])
     np.savez_compressed(os.path.join(OUT, 'reblock.npz'), **out)
 
 

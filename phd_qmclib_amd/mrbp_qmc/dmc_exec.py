@@ -12,9 +12,26 @@ from ..qmc_exec import proc as proc_base
 from . import dmc, model
 from .vmc_exec import ModelSysConfSpec, _as_int, _opt
 
-__all__ = ['ModelSysConfSpec', 'Proc', 'ProcInput', 'ProcResult']
+__all__ = ['DensityEstSpec', 'ModelSysConfSpec', 'Proc', 'ProcInput',
+           'ProcResult', 'SSFEstSpec']
 
 ProcInputError = proc_base.ProcInputError
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class DensityEstSpec:
+    """dmc_exec/proc.py:71-81."""
+    num_bins: int = attr.ib(converter=_as_int,
+                            validator=attr.validators.instance_of(int))
+    as_pure_est: bool = attr.ib(default=True, converter=bool)
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class SSFEstSpec:
+    """dmc_exec/proc.py:84-94."""
+    num_modes: int = attr.ib(converter=_as_int,
+                             validator=attr.validators.instance_of(int))
+    as_pure_est: bool = attr.ib(default=True, converter=bool)
 
 
 @attr.s(auto_attribs=True)
@@ -86,7 +103,16 @@ class Proc:
             if old in cfg:
                 cfg[new] = cfg.pop(old)
         model_spec = model.Spec(**cfg.pop('model_spec'))
-        return cls(model_spec=model_spec, **cfg)
+        dens_cfg = cfg.pop('density_spec', None)
+        dens = DensityEstSpec(**dens_cfg) if dens_cfg is not None else None
+        ssf_cfg = cfg.pop('ssf_spec', None)
+        ssf = None
+        if ssf_cfg is not None:
+            ssf_cfg = dict(ssf_cfg)
+            ssf_cfg.pop('pfw_num_time_steps', None)
+            ssf = SSFEstSpec(**ssf_cfg)
+        return cls(model_spec=model_spec, density_spec=dens, ssf_spec=ssf,
+                   **cfg)
 
     def as_config(self):
         return attr.asdict(self, filter=attr.filters.exclude(type(None)))
@@ -101,13 +127,20 @@ class Proc:
 
     @property
     def sampling(self) -> dmc.Sampling:
-        if self.should_eval_density or self.should_eval_ssf:
-            raise NotImplementedError(
-                'density / structure-factor estimators are not part of the '
-                'accelerated path yet (SURVEY.md 8f, row f1)')
+        """dmc_exec/proc.py:336-371: the forward walking of the pure
+        estimators spans one block."""
+        pfw = self.num_time_steps_block
+        dens = ssf = None
+        if self.should_eval_density:
+            dens = dmc.DensityEstSpec(self.density_spec.num_bins,
+                                      self.density_spec.as_pure_est, pfw)
+        if self.should_eval_ssf:
+            ssf = dmc.SSFEstSpec(self.ssf_spec.num_modes,
+                                 self.ssf_spec.as_pure_est, pfw)
         return dmc.Sampling(self.model_spec, self.time_step,
                             self.max_num_walkers, self.target_num_walkers,
-                            self.num_walkers_control_factor, self.rng_seed)
+                            self.num_walkers_control_factor, self.rng_seed,
+                            density_est_spec=dens, ssf_est_spec=ssf)
 
     def build_result(self, state, data):
         return ProcResult(state, self, data)

@@ -11,8 +11,9 @@ import numpy as np
 
 from ...stats import reblock
 
-__all__ = ['EnergyBlocks', 'NumWalkersBlocks', 'PropBlocks',
-           'PropsDataBlocks', 'SamplingData', 'UnWeightedPropBlocks',
+__all__ = ['DensityBlocks', 'EnergyBlocks', 'NumWalkersBlocks', 'PropBlocks',
+           'SSFBlocks', 'SSFPartBlocks',
+           'PropsDataBlocks', 'PropsDataSeries', 'SamplingData', 'UnWeightedPropBlocks',
            'WeightBlocks']
 
 
@@ -131,6 +132,105 @@ class EnergyBlocks(PropBlocks):
         return cls(e, w)
 
 
+def _est_totals(nts_block, data, weight, reduce_data, as_pure_est,
+                pure_est_reduce_factor):
+    """Block totals of an estimator (qmc_exec/data/dmc.py:329-371, 425-466):
+    mixed estimators sum over the block, pure ones take the last time step."""
+    data, weight = np.asarray(data), np.asarray(weight)
+    if not as_pure_est:
+        if reduce_data:
+            return data.sum(axis=1), weight.sum(axis=1)[:, np.newaxis]
+        return data, weight[:, np.newaxis]
+    if reduce_data:
+        return (data[:, nts_block - 1, :],
+                weight[:, nts_block - 1][:, np.newaxis])
+    return data, (weight * pure_est_reduce_factor)[:, np.newaxis]
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class SetPropBlocks(PropBlocks):
+    """Weighted block totals of a vector-valued property (one column per bin
+    or momentum); statistics per column through `reblock.OTFSet`."""
+    totals: np.ndarray
+    weight_totals: np.ndarray
+
+    @property
+    def reblock(self):
+        return reblock.OTFSet.from_non_obj_data(self.totals)
+
+    @property
+    def weight_reblock(self):
+        if self.weight_totals is None:
+            return None
+        return reblock.OTFSet.from_non_obj_data(self.weight_totals)
+
+    @property
+    def cross_weight_reblock(self):
+        if self.weight_totals is None:
+            return None
+        return reblock.OTFSet.from_non_obj_data(self.totals *
+                                                self.weight_totals)
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class DensityBlocks(SetPropBlocks):
+    """Density data in blocks (qmc_exec/data/dmc.py:321-393)."""
+    totals: np.ndarray
+    weight_totals: np.ndarray
+
+    @classmethod
+    def from_data(cls, num_time_steps_block, density_data, props_data,
+                  reduce_data=True, as_pure_est=True,
+                  pure_est_reduce_factor=None):
+        return cls(*_est_totals(num_time_steps_block, density_data,
+                                props_data.weight, reduce_data, as_pure_est,
+                                pure_est_reduce_factor))
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class SSFPartBlocks(SetPropBlocks):
+    totals: np.ndarray
+    weight_totals: np.ndarray
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class SSFBlocks:
+    """Structure factor data in blocks (qmc_exec/data/dmc.py:495-621):
+    S(k) = <|rho_k|^2> - <Re rho_k>^2 - <Im rho_k>^2."""
+    fdk_sqr_abs_part: SSFPartBlocks
+    fdk_real_part: SSFPartBlocks
+    fdk_imag_part: SSFPartBlocks
+
+    @classmethod
+    def from_data(cls, num_time_steps_block, ssf_data, props_data,
+                  reduce_data=True, as_pure_est=True,
+                  pure_est_reduce_factor=None):
+        totals, w = _est_totals(num_time_steps_block, ssf_data,
+                                props_data.weight, reduce_data, as_pure_est,
+                                pure_est_reduce_factor)
+        return cls(SSFPartBlocks(totals[:, :, 0], w),
+                   SSFPartBlocks(totals[:, :, 1], w),
+                   SSFPartBlocks(totals[:, :, 2], w))
+
+    @property
+    def mean(self):
+        return (self.fdk_sqr_abs_part.mean - self.fdk_real_part.mean ** 2 -
+                self.fdk_imag_part.mean ** 2)
+
+    @property
+    def mean_error(self):
+        re, im = self.fdk_real_part, self.fdk_imag_part
+        return (self.fdk_sqr_abs_part.mean_error +
+                2 * (re.mean * re.mean_error + im.mean * im.mean_error))
+
+    def __add__(self, other):
+        if not isinstance(other, SSFBlocks):
+            return NotImplemented
+        return SSFBlocks(self.fdk_sqr_abs_part + other.fdk_sqr_abs_part,
+                         self.fdk_real_part + other.fdk_real_part,
+                         self.fdk_imag_part + other.fdk_imag_part)
+
+
 @attr.s(auto_attribs=True, frozen=True)
 class PropsDataBlocks:
     energy: EnergyBlocks
@@ -141,6 +241,19 @@ class PropsDataBlocks:
 
 
 @attr.s(auto_attribs=True, frozen=True)
+class PropsDataSeries:
+    """Per-time-step data kept with `keep_iter_data`
+    (qmc_exec/data/dmc.py:624-660)."""
+    iter_props_blocks: t.Any
+    ssf_blocks: t.Optional[np.ndarray] = None
+
+    @property
+    def props(self):
+        p = self.iter_props_blocks
+        return type(p)(*[np.hstack(getattr(p, f)) for f in p._fields])
+
+
+@attr.s(auto_attribs=True, frozen=True)
 class SamplingData:
     blocks: PropsDataBlocks
-    series: t.Optional[t.Any] = None
+    series: t.Optional[PropsDataSeries] = None

@@ -71,7 +71,8 @@ def exec_vmc(proc, proc_input):
 
 
 def exec_dmc(proc, proc_input):
-    """qmc_exec/dmc/proc.py:136-415 (energy / weight / walkers series)."""
+    """qmc_exec/dmc/proc.py:136-415: energy / weight / walkers series and the
+    density / S(k) estimators of the kept blocks."""
     from ..mrbp_qmc.dmc_exec import ProcInput
     num_blocks, nts = proc.num_blocks, proc.num_time_steps_block
     keep = proc.keep_iter_data
@@ -82,6 +83,7 @@ def exec_dmc(proc, proc_input):
     if not isinstance(proc_input, ProcInput):
         raise ProcInputError('the input data for the DMC procedure is '
                              'not valid')
+    dens_spec, ssf_spec = proc.density_spec, proc.ssf_spec
     blocks_iter = proc.sampling.blocks(proc_input.state, nts, burn)
     block = None
     try:
@@ -91,24 +93,57 @@ def exec_dmc(proc, proc_input):
         e, w = np.zeros(shape), np.zeros(shape)
         nw = np.zeros(shape, dtype=np.uint64)
         re, ae = np.zeros(shape), np.zeros(shape)
+        dens = ssf = None
+        if dens_spec is not None:
+            nb = dens_spec.num_bins
+            dens = np.zeros((num_blocks, nts, nb, 1) if keep
+                            else (num_blocks, nb, 1))
+        if ssf_spec is not None:
+            nm = ssf_spec.num_modes
+            ssf = np.zeros((num_blocks, nts, nm, 3) if keep
+                           else (num_blocks, nm, 3))
+        pure_fac = np.ones(num_blocks)
         for b, block in enumerate(islice(blocks_iter, num_blocks)):
             p = block.iter_props
             if keep:
                 e[b], w[b], nw[b] = p.energy, p.weight, p.num_walkers
                 re[b], ae[b] = p.ref_energy, p.accum_energy
+                if dens is not None:
+                    dens[b] = block.iter_density
+                if ssf is not None:
+                    ssf[b] = block.iter_ssf
             else:
-                e[b], w[b] = p.energy.sum(), p.weight.sum()
+                wsum = p.weight.sum()
+                e[b], w[b] = p.energy.sum(), wsum
                 nw[b] = p.num_walkers.sum()
                 re[b], ae[b] = p.ref_energy[-1], p.accum_energy[-1]
+                pure_fac[b] = p.num_walkers[nts - 1] / wsum
+                if dens is not None:
+                    dens[b] = (block.iter_density[nts - 1]
+                               if dens_spec.as_pure_est
+                               else block.iter_density.sum(axis=0))
+                if ssf is not None:
+                    ssf[b] = (block.iter_ssf[nts - 1] if ssf_spec.as_pure_est
+                              else block.iter_ssf.sum(axis=0))
     finally:
         blocks_iter.close()
     exec_logger.info('DMC sampling completed.')
     last_state = None if block is None else block.last_state
     props = dmc_base.PropsData(e, w, nw, re, ae)
     reduce_data = bool(keep)
+    dens_blocks = ssf_blocks = None
+    if dens is not None:
+        dens_blocks = dmc_data.DensityBlocks.from_data(
+            nts, dens[..., 0], props, reduce_data, dens_spec.as_pure_est,
+            pure_fac)
+    if ssf is not None:
+        ssf_blocks = dmc_data.SSFBlocks.from_data(
+            nts, ssf, props, reduce_data, ssf_spec.as_pure_est, pure_fac)
     blocks = dmc_data.PropsDataBlocks(
         dmc_data.EnergyBlocks.from_data(props, reduce_data),
         dmc_data.WeightBlocks.from_data(props, reduce_data),
-        dmc_data.NumWalkersBlocks.from_data(props, reduce_data))
-    data = dmc_data.SamplingData(blocks, props if keep else None)
+        dmc_data.NumWalkersBlocks.from_data(props, reduce_data),
+        dens_blocks, ssf_blocks)
+    data = dmc_data.SamplingData(
+        blocks, dmc_data.PropsDataSeries(props, ssf) if keep else None)
     return proc.build_result(last_state, data)

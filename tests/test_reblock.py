@@ -88,3 +88,34 @@ def test_concat_blocks():
     assert len(c) == 10 and isinstance(c, dmc_data.EnergyBlocks)
     assert len(dmc_data.WeightBlocks(np.ones(3)) +
                dmc_data.WeightBlocks(np.ones(5))) == 8
+
+
+def test_set_reblocking_and_estimator_containers(golden_reblock):
+    """2-D reblocking (OTFSet) and the S(k) block containers against the
+    reference (stats/reblock.py:759-923, qmc_exec/data/dmc.py:396-621)."""
+    g = golden_reblock
+    x2, w2 = g['set/x'], g['set/w']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        st = rb.OTFSet.from_non_obj_data(x2)
+        assert np.array_equal(st.block_sizes, g['set/block_sizes'])
+        assert np.array_equal(st.num_blocks, g['set/num_blocks'])
+        assert np.allclose(st.means, g['set/means'], rtol=1e-13)
+        assert np.allclose(st.vars, g['set/vars'], rtol=1e-9)
+        assert np.allclose(st.iac_times, g['set/iac_times'], rtol=1e-9)
+        assert np.array_equal(st.opt_block_size, g['set/opt_block_size'])
+        assert np.allclose(st.opt_iac_time, g['set/opt_iac_time'], rtol=1e-9)
+        assert np.allclose(st.eff_size, g['set/eff_size'], rtol=1e-9)
+        assert np.allclose(st.mean_eff_error, g['set/mean_eff_error'],
+                           rtol=1e-9)
+        assert np.isclose(st[2].mean, g['set/means'][2, 0], rtol=1e-13)
+        pb = dmc_data.SSFPartBlocks(x2 * w2[:, None], w2[:, None])
+        assert np.allclose(pb.mean, g['set/part_mean'], rtol=1e-12)
+        assert np.allclose(pb.mean_error, g['set/part_mean_error'], rtol=1e-7)
+
+        class P:
+            weight = w2
+        sb = dmc_data.SSFBlocks.from_data(4, g['set/ssf3'], P,
+                                          reduce_data=False, as_pure_est=False)
+        assert np.allclose(sb.mean, g['set/ssf_mean'], rtol=1e-10)
+        assert np.allclose(sb.mean_error, g['set/ssf_mean_error'], rtol=1e-7)
