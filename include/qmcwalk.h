@@ -144,6 +144,9 @@ int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_energy,
                       double *sum_energy2, int64_t *num_accepted,
                       double *series_wf, double *series_energy,
                       uint8_t *series_stat, double *series_pos);
+/* Device addresses of the chain state, pos[W][N] and wf[W] (VMC -> DMC
+ * hand-off without a host round trip, tests/mrbp_qmc/test_dmc.py:76-83). */
+int qmc_vmc_state_dev(qmc_vmc *v, double **pos, double **wf);
 /* Device addresses of the per-chain block sums of the last block
  * (sum_e[W], sum_e2[W], n_acc[W]) for on-device reductions / collectives. */
 int qmc_vmc_block_sums_dev(qmc_vmc *v, double **sum_e, double **sum_e2,
@@ -162,6 +165,9 @@ void qmc_dmc_destroy(qmc_dmc *d);
  * use_ref_energy.  The caller has already applied `[-target_num_walkers:]`. */
 int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
                       int use_ref_energy, double ref_energy);
+/* build_state from positions already in HBM (e.g. qmc_vmc_state_dev). */
+int qmc_dmc_set_state_dev(qmc_dmc *d, int64_t nw, const double *pos_dev,
+                          int use_ref_energy, double ref_energy);
 /* Restart from a yielded State (qmc_base/dmc.py:707-716): confs[nw][2][N],
  * energy[nw], weight[nw] copied as they are; slot_energy[maxw] (or NULL) is the
  * whole props.energy array of that State. */

@@ -79,12 +79,15 @@ SIGNATURES = {
     'qmc_vmc_get_state': (C.c_int, [_vp, _dp, _dp, _dp]),
     'qmc_vmc_run_block': (C.c_int, [_vp, C.c_int64, _dp, _dp, _i64p, _dp, _dp,
                                     _u8p, _dp]),
+    'qmc_vmc_state_dev': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     'qmc_vmc_block_sums_dev': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp),
                                          C.POINTER(_vp)]),
     'qmc_vmc_set_tape': (C.c_int, [_vp, _dp, C.c_int64]),
     'qmc_dmc_create': (C.c_int, [_vp, C.POINTER(DmcParams), C.POINTER(_vp)]),
     'qmc_dmc_destroy': (None, [_vp]),
     'qmc_dmc_set_state': (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_double]),
+    'qmc_dmc_set_state_dev': (C.c_int, [_vp, C.c_int64, _vp, C.c_int,
+                                        C.c_double]),
     'qmc_dmc_set_full_state': (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp, _dp,
                                          C.c_double]),
     'qmc_dmc_run_block': (C.c_int, [_vp, C.c_int64, _dp, _dp, _u64p, _dp,

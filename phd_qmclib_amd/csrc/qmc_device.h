@@ -380,30 +380,27 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 #define QMC_KSTEP(k, LAST)                                                    \
         {                                                                     \
             const bool count_pair = !(LAST) || gl < G / 2;                    \
-            PTab pb[P];                                                       \
-            double pz[P];                                                     \
-            bool pok[P];                                                      \
+            /* partner-major order: one partner table live at a time, so the  \
+               P = 4, 8 shapes do not hold P tables in registers */           \
             _Pragma("unroll")                                                 \
             for (int b = 0; b < P; ++b) {                                     \
-                int idx = b * 2 * G + gl + G - (k);                           \
-                pb[b].s = lS[idx]; pb[b].c = lC[idx];                         \
-                pb[b].su = lSU[idx]; pb[b].cu = lCU[idx];                     \
-                pz[b] = ZCLASS ? lZ[idx] : 0.0;                               \
+                PTab pb;                                                      \
+                const int idx = b * 2 * G + gl + G - (k);                     \
+                pb.s = lS[idx]; pb.c = lC[idx];                               \
+                pb.su = lSU[idx]; pb.cu = lCU[idx];                           \
+                const double pz = ZCLASS ? lZ[idx] : 0.0;                     \
                 int pl = gl - (k); if (pl < 0) pl += G;                       \
-                pok[b] = !PAD || (pl + G * b) < n;                            \
-            }                                                                 \
-            _Pragma("unroll")                                                 \
-            for (int a = 0; a < P; ++a) {                                     \
+                const bool pok = !PAD || (pl + G * b) < n;                    \
                 _Pragma("unroll")                                             \
-                for (int b = 0; b < P; ++b) {                                 \
+                for (int a = 0; a < P; ++a) {                                 \
                     double q, Y; bool sh; unsigned long long shm;            \
-                    pair_core<ZCLASS>(pc, t[a], aks[a], akc[a], z[a], pb[b],  \
-                                      pz[b], q, Y, sh, shm);                  \
+                    pair_core<ZCLASS>(pc, t[a], aks[a], akc[a], z[a], pb,     \
+                                      pz, q, Y, sh, shm);                     \
                     /* G = 64: the lower half of the lanes is bits 0..31 */   \
                     if (WAVE_COUNT)                                           \
                         ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \
                                                    : shm);                    \
-                    if (!PAD || (ok[a] && pok[b])) {                          \
+                    if (!PAD || (ok[a] && pok)) {                             \
                         F[a] += q;                                            \
                         if (!(LAST)) T[b] -= q;                               \
                         if (!(LAST) || count_pair) { QMC_TALLY(q, Y, sh); }   \

@@ -1177,6 +1177,14 @@ extern "C" int qmc_vmc_set_tape(qmc_vmc *v, const double *tape, int64_t steps)
     return 0;
 }
 
+extern "C" int qmc_vmc_state_dev(qmc_vmc *v, double **pos, double **wf)
+{
+    if (!v) return fail("null argument");
+    if (pos) *pos = v->pos;
+    if (wf) *wf = v->wf;
+    return 0;
+}
+
 extern "C" int qmc_vmc_block_sums_dev(qmc_vmc *v, double **se, double **se2,
                                       int64_t **na)
 {
@@ -1378,8 +1386,9 @@ static int dmc_reset_ctl(qmc_dmc *d, long long nw, double ref_energy)
     return 0;
 }
 
-extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
-                                 int use_ref, double ref_energy)
+static int dmc_set_state_impl(qmc_dmc *d, int64_t nw, const double *pos,
+                              bool pos_on_device, int use_ref,
+                              double ref_energy)
 {
     if (!d || !pos) return fail("qmc_dmc_set_state: null argument");
     if (nw <= 0 || nw > d->maxw)
@@ -1395,7 +1404,8 @@ extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
     }
     HIP_TRY(hipMemsetAsync(d->eslot, 0, W * sizeof(double), e->stream));
     HIP_TRY(hipMemcpyAsync(d->pos[0], pos, (size_t)nw * n * sizeof(double),
-                           hipMemcpyHostToDevice, e->stream));
+                           pos_on_device ? hipMemcpyDeviceToDevice
+                                         : hipMemcpyHostToDevice, e->stream));
     PrepArgs a{ d->pos[0], d->drift[0], d->energy[0], (long long)nw };
     int rc = dispatch_shape<LaunchPrep>(e, a);
     if (rc) return rc;
@@ -1414,6 +1424,19 @@ extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
         ref_energy = se / (double)nw;
     }
     return dmc_reset_ctl(d, nw, ref_energy);
+}
+
+extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
+                                 int use_ref, double ref_energy)
+{
+    return dmc_set_state_impl(d, nw, pos, false, use_ref, ref_energy);
+}
+
+extern "C" int qmc_dmc_set_state_dev(qmc_dmc *d, int64_t nw,
+                                     const double *pos_dev, int use_ref,
+                                     double ref_energy)
+{
+    return dmc_set_state_impl(d, nw, pos_dev, true, use_ref, ref_energy);
 }
 
 extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,

@@ -195,6 +195,12 @@ class VmcEnsemble:
             out.update(wf_abs_log=swf, energy=sen, move_stat=sst.astype(bool))
         return out
 
+    def state_dev(self):
+        """Device addresses (ints) of pos[W, N] and wf[W]."""
+        a, b = C.c_void_p(), C.c_void_p()
+        check(self._lib.qmc_vmc_state_dev(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def block_sums_dev(self):
         """Device addresses (ints) of sum_e[W], sum_e2[W], n_acc[W]."""
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -263,6 +269,19 @@ class DmcEnsemble:
             raise ValueError('pos must have shape (nw, boson_number)')
         check(self._lib.qmc_dmc_set_state(
             self._h, pos.shape[0], ptr(pos), int(ref_energy is not None),
+            float(ref_energy if ref_energy is not None else 0.0)))
+
+    def set_state_from_vmc(self, vmc: 'VmcEnsemble', num_walkers=None,
+                           ref_energy: t.Optional[float] = None):
+        """build_state from the current configurations of a VMC ensemble on
+        the same engine, device to device (the first `num_walkers` chains)."""
+        nw = vmc.num_chains if num_walkers is None else int(num_walkers)
+        if nw > vmc.num_chains:
+            raise ValueError('more walkers requested than chains')
+        self.engine.sync()
+        pos_ptr, _ = vmc.state_dev()
+        check(self._lib.qmc_dmc_set_state_dev(
+            self._h, nw, pos_ptr, int(ref_energy is not None),
             float(ref_energy if ref_energy is not None else 0.0)))
 
     def set_full_state(self, confs, energy, weight, ref_energy: float,

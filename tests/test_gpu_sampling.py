@@ -298,3 +298,47 @@ def test_dmc_estimators_through_sampling_and_proc():
     # the reference transports the pure density by slot index (not along the
     # lineage), so slots that joined late dilute the normalisation slightly
     assert 14.0 < dn.mean.sum() <= 16.0 + 1e-9
+
+
+def test_vmc_to_dmc_handoff_on_device():
+    """VMC chains seed the DMC population without a host round trip
+    (the pipeline of tests/mrbp_qmc/test_dmc.py:76-83)."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
+    spec = box(16)
+    eng = ModelEngine(spec.cfc_spec)
+    rng = np.random.RandomState(4)
+    v = VmcEnsemble(eng, 500, 0.125, rng_seed=6)
+    v.set_state(16 * rng.random_sample((500, 16)))
+    v.run_block(40, sums=False)
+    pos = v.get_state()[0]
+    a = DmcEnsemble(eng, 1e-3, 512, 480, 0.5, rng_seed=6)
+    a.set_state_from_vmc(v, 480)
+    b = DmcEnsemble(eng, 1e-3, 512, 480, 0.5, rng_seed=6)
+    b.set_state(pos[:480])
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa.confs, sb.confs) and sa.ref_energy == sb.ref_energy
+    assert np.array_equal(a.run_block(5).energy, b.run_block(5).energy)
+    for h in (a, b, v):
+        h.close()
+    eng.close()
+
+
+def test_vmc_ndf_gaussian_proposal(oracle, golden_params):
+    """mrbp_qmc/vmc_ndf.py:23-51: Gaussian proposal with sigma = sqrt(dt);
+    device chain vs the oracle's Gaussian chain on the same Philox stream."""
+    from phd_qmclib_amd import mrbp_qmc
+    from .conftest import oracle_model
+    spec = box(16)
+    smp = mrbp_qmc.vmc.NDFSampling(spec, time_step=4e-3, rng_seed=21)
+    assert abs(smp._proposal_width() - np.sqrt(4e-3)) < 1e-16
+    np.random.seed(9)
+    ini = smp.build_state(spec.init_get_sys_conf())
+    blk = next(smp.blocks(40, ini))
+    m = oracle_model(oracle, golden_params, 'box16')
+    ch = oracle.VmcChain(m, ini.sys_conf[0], np.sqrt(4e-3), seed=21, chain=0,
+                         gaussian=True)
+    wf, en, st, acc = ch.run(40)
+    assert np.array_equal(st, blk.iter_props.move_stat)
+    assert np.allclose(en, blk.iter_props.energy, rtol=1e-9)
+    assert np.allclose(wf, blk.iter_props.wf_abs_log, rtol=1e-9)
+    assert 0.2 < blk.accept_rate <= 1.0

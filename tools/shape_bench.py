@@ -1,0 +1,29 @@
+"""Throughput of the DMC step and VMC step for several N (development tool)."""
+import os, sys, time
+from math import pi
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
+from phd_qmclib_amd.mrbp_qmc import Spec
+
+for n, W in [(16, 1 << 20), (24, 1 << 19), (64, 1 << 18), (100, 1 << 17), (128, 1 << 17), (256, 1 << 15), (512, 1 << 13)]:
+    spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
+                boson_number=n, supercell_size=n, tbf_contact_cutoff=0.25 * n)
+    eng = ModelEngine(spec.cfc_spec, device=0)
+    rng = np.random.RandomState(1)
+    pos = n * rng.random_sample((W, n))
+    v = VmcEnsemble(eng, W, 0.125, rng_seed=1)
+    v.set_state(pos)
+    v.run_block(4, sums=False); eng.sync()
+    eng.timer_start(); v.run_block(8, sums=False); ms = eng.timer_stop()
+    vr = W * 8 / (ms * 1e-3)
+    maxw = ((W * 512 // 480) + 255) // 256 * 256
+    d = DmcEnsemble(eng, 6.25e-4, maxw, W, 0.5, rng_seed=1)
+    d.set_state(v.get_state()[0])
+    d.run_block(4, read=False); eng.sync()
+    eng.timer_start(); d.run_block(8, read=False); ms = eng.timer_stop()
+    ser = d.read_series(8)
+    dr = float(ser.num_walkers.sum()) / (ms * 1e-3)
+    pairs = n * (n - 1) / 2
+    print(f'N={n:4d} W={W:8d}  VMC {vr:10.3e} steps/s ({vr*pairs:9.3e} pairs/s)   DMC {dr:10.3e} steps/s ({dr*pairs:9.3e} pairs/s)', flush=True)
+    d.close(); v.close(); eng.close()
