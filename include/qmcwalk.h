@@ -144,8 +144,11 @@ int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_energy,
                       double *sum_energy2, int64_t *num_accepted,
                       double *series_wf, double *series_energy,
                       uint8_t *series_stat, double *series_pos);
-/* Device addresses of the chain state, pos[W][N] and wf[W] (VMC -> DMC
- * hand-off without a host round trip, tests/mrbp_qmc/test_dmc.py:76-83). */
+/* Device addresses of the chain state, pos[W][N] and wf[W].  NOTE: on the
+ * device the particles of a configuration are kept in position order (an
+ * internal label array maps lanes back to the caller's particle indices;
+ * every host-facing call un-permutes).  Symmetric functions of a
+ * configuration can be evaluated on these buffers directly. */
 int qmc_vmc_state_dev(qmc_vmc *v, double **pos, double **wf);
 /* Device addresses of the per-chain block sums of the last block
  * (sum_e[W], sum_e2[W], n_acc[W]) for on-device reductions / collectives. */
@@ -165,9 +168,13 @@ void qmc_dmc_destroy(qmc_dmc *d);
  * use_ref_energy.  The caller has already applied `[-target_num_walkers:]`. */
 int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
                       int use_ref_energy, double ref_energy);
-/* build_state from positions already in HBM (e.g. qmc_vmc_state_dev). */
+/* build_state from positions already in HBM; set_state_from_vmc takes the
+ * first nw chains of a VMC ensemble of the same engine (VMC -> DMC hand-off
+ * without a host round trip, tests/mrbp_qmc/test_dmc.py:76-83). */
 int qmc_dmc_set_state_dev(qmc_dmc *d, int64_t nw, const double *pos_dev,
                           int use_ref_energy, double ref_energy);
+int qmc_dmc_set_state_from_vmc(qmc_dmc *d, qmc_vmc *v, int64_t nw,
+                               int use_ref_energy, double ref_energy);
 /* Restart from a yielded State (qmc_base/dmc.py:707-716): confs[nw][2][N],
  * energy[nw], weight[nw] copied as they are; slot_energy[maxw] (or NULL) is the
  * whole props.energy array of that State. */
@@ -208,7 +215,7 @@ int qmc_dmc_read_series(qmc_dmc *d, int64_t nsteps, double *energy,
                         double *weight, uint64_t *num_walkers,
                         double *ref_energy, double *accum_energy);
 /* Population rebalance: pack walkers [first, first+count) of the current
- * population into buf_dev[count][2N+2] (pos, drift, energy, weight) / append
+ * population into buf_dev[count][3N+2] (pos, drift, labels, energy, weight) / append
  * `count` packed walkers; truncate drops the tail. */
 int qmc_dmc_num_walkers(qmc_dmc *d, int64_t *nw);
 int qmc_dmc_export_walkers(qmc_dmc *d, int64_t first, int64_t count,

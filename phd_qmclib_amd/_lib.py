@@ -88,6 +88,8 @@ SIGNATURES = {
     'qmc_dmc_set_state': (C.c_int, [_vp, C.c_int64, _dp, C.c_int, C.c_double]),
     'qmc_dmc_set_state_dev': (C.c_int, [_vp, C.c_int64, _vp, C.c_int,
                                         C.c_double]),
+    'qmc_dmc_set_state_from_vmc': (C.c_int, [_vp, _vp, C.c_int64, C.c_int,
+                                             C.c_double]),
     'qmc_dmc_set_full_state': (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp, _dp,
                                          C.c_double]),
     'qmc_dmc_run_block': (C.c_int, [_vp, C.c_int64, _dp, _dp, _u64p, _dp,

@@ -133,6 +133,53 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
+// Lane order = position order.  Bosons are identical, so which lane holds which
+// particle is free; when the lanes of a group hold the particles in (cyclic)
+// position order, the lanes met at rotation step k all sit at about the same
+// separation k L / N and the short-range branch of the pair loop becomes
+// (nearly) wave-uniform: whole steps skip it through s_cbranch_execz (+10 %
+// measured).  A label per lane remembers the particle's original index: RNG
+// counters, tapes and every array handed back to the host use the label, so
+// results do not depend on the lane order (only summation order does).
+// One odd-even transposition pass per time step keeps the order as particles
+// diffuse; the comparison is on the minimum-image separation, so a particle
+// that crosses the box boundary stays correctly (cyclically) ordered.
+template <int G, int P>
+__device__ __forceinline__ void resort_step(double (&z)[P], int (&lab)[P],
+                                            int gl, unsigned parity, int n,
+                                            double L, double half_L)
+{
+    const int lane = threadIdx.x & 63, base = lane - gl;
+    // partner in the row: even phase (0,1)(2,3)..; odd phase (1,2)(3,4)..
+    // and, across the row seam, (G-1 of row a, 0 of row a+1) cyclically
+    int pg = (parity & 1u) ? ((gl & 1) ? gl + 1 : gl - 1) : (gl ^ 1);
+    const bool wrap_hi = pg >= G, wrap_lo = pg < 0;
+    if (wrap_hi) pg = 0;
+    if (wrap_lo) pg = G - 1;
+    double z0[P]; int l0[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) { z0[a] = z[a]; l0[a] = lab[a]; }
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+        const int want = wrap_hi ? (a + 1) % P : (wrap_lo ? (a + P - 1) % P : a);
+        double zp = 0.0; int lp = 0;
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            // (shuffles are executed by every lane; each keeps the row it needs)
+            double zz = __shfl(z0[b], base + pg, 64);
+            int ll = __shfl(l0[b], base + pg, 64);
+            if (b == want) { zp = zz; lp = ll; }
+        }
+        const bool valid = (gl + G * a) < n && (pg + G * want) < n;
+        // "lower" = the element whose rank comes first in the cyclic order
+        const bool lower = wrap_hi ? true : (wrap_lo ? false : gl < pg);
+        double d = lower ? zp - z0[a] : z0[a] - zp;   // upper minus lower
+        if (d > half_L) d -= L;
+        if (d < -half_L) d += L;
+        if (valid && d < 0.0) { z[a] = zp; lab[a] = lp; }
+    }
+}
+
 // Per-particle table entry kept in registers by the owner and published to LDS.
 struct PTab {
     double s, c;    // sin/cos(pi z / L)

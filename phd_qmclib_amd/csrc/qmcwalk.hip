@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -158,7 +159,8 @@ prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
 // the host the kernel has the register footprint of `evaluate_kernel` and the
 // state round trip is ~1 KB per chain-step, far below the HBM roofline.)
 struct VmcArgs {
-    double *pos;          // [W][N] in/out
+    double *pos;          // [W][N] in/out, lane (position) order
+    unsigned short *label;// [W][N] in/out, original index of each lane's particle
     double *wf;           // [W]    in/out  log|psi|
     double *ecarry;       // [W]    in/out  energy carried to rejected moves
     double *sum_e, *sum_e2;   // [W] running block sums
@@ -202,33 +204,41 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     const bool forced = a.forced != 0;
 
     double z[P], zn[P];
+    int lab[P], labn[P];      // original particle index held by each lane
     double ua = 1.0;          // accept uniform (particle 0's spare double)
+    double uas[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = gl + G * p;
+        uas[p] = -1.0;
         z[p] = (i < n) ? a.pos[wr * n + i] : 0.0;
+        lab[p] = (i < n) ? (int)a.label[wr * n + i] : i;
+        labn[p] = lab[p];
+        const unsigned li = (unsigned)lab[p];
         double d = 0.0;
         if (!forced && i < n) {
             if (!LEAN && a.tape) {
-                double tv = a.tape[(wr * a.tape_steps + a.tape_idx) * (n + 1) + i];
+                double tv = a.tape[(wr * a.tape_steps + a.tape_idx) * (n + 1) + li];
                 d = a.gaussian ? a.move_spread * tv
                                : (tv - 0.5) * a.move_spread;
             } else if (!LEAN && a.gaussian) {
                 double g0, g1;
-                philox_normal2(a.seed, slot, a.step, (unsigned)i,
-                               STREAM_VMC_MOVE, g0, g1);
+                philox_normal2(a.seed, slot, a.step, li, STREAM_VMC_MOVE, g0,
+                               g1);
                 d = a.move_spread * g0;
             } else {
                 double u0, u1;
-                philox_uniform2(a.seed, slot, a.step, (unsigned)i,
-                                STREAM_VMC_MOVE, u0, u1);
+                philox_uniform2(a.seed, slot, a.step, li, STREAM_VMC_MOVE, u0,
+                                u1);
                 d = (u0 - 0.5) * a.move_spread;
-                if (p == 0) ua = u1;
+                // the accept draw is the spare double of particle 0
+                uas[p] = (li == 0u) ? u1 : -1.0;
             }
         }
         // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
         zn[p] = forced ? z[p] : wrap_box(z[p] + d, m.L);
     }
+    if (!forced) resort_step<G, P>(zn, labn, gl, a.step, n, m.L, m.half_L);
     double F[P], ei[P], e_new, wf_new;
     eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
                                             wf_new);
@@ -240,8 +250,14 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             philox_uniform2(a.seed, slot, a.step, 0u, STREAM_VMC_ACCEPT, ua,
                             u1);
         } else {
-            // lane 0 of the group holds particle 0
-            ua = __shfl(ua, (threadIdx.x & 63) - gl, 64);
+            // exactly one lane of the group holds particle 0 (ua >= 0 there)
+            double best = -1.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) best = fmax(best, uas[p]);
+#pragma unroll
+            for (int msk = 1; msk < G; msk <<= 1)
+                best = fmax(best, __shfl_xor(best, msk, 64));
+            ua = best;
         }
     }
     if (!active) return;
@@ -254,7 +270,10 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = gl + G * p;
-            if (i < n && !forced) a.pos[w * n + i] = zn[p];
+            if (i < n && !forced) {
+                a.pos[w * n + i] = zn[p];
+                a.label[w * n + i] = (unsigned short)labn[p];
+            }
         }
         if (!forced) wf_cur = wf_new;
         e_cur = e_new;       // energy only re-evaluated on accepted moves
@@ -263,7 +282,10 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = gl + G * p;
-            if (i < n) a.ser_pos[(a.y * a.W + w) * n + i] = acc ? zn[p] : z[p];
+            // series in the original particle order
+            if (i < n)
+                a.ser_pos[(a.y * a.W + w) * n + (acc ? labn[p] : lab[p])] =
+                    acc ? zn[p] : z[p];
         }
     }
     if (gl == 0) {
@@ -457,6 +479,8 @@ dmc_local_sums_kernel(const double *block_esum, DmcCtl *ctl, double *partial)
 struct EvolveArgs {
     const double *ppos, *pdrift, *penergy;   // parents
     double *cpos, *cdrift, *cenergy, *cweight; // children
+    const unsigned short *plabel;             // parents' lane -> particle index
+    unsigned short *clabel;
     double *eslot;            // energy the slot held in the previous iteration
     const long long *ref;
     const DmcCtl *ctl;
@@ -496,27 +520,32 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     const long long par = a.ref[sr];
 
     double z[P];
+    int lab[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = gl + G * p;
         double zz = 0.0;
+        lab[p] = i;
         if (i < n) {
             double z0 = a.ppos[par * n + i];
             double f0 = a.pdrift[par * n + i];
+            // random numbers belong to the particle (label), not to the lane
+            const int li = (int)a.plabel[par * n + i];
+            lab[p] = li;
             double g;
             if (a.g_tape) {
-                g = a.g_tape[sr * n + i];
+                g = a.g_tape[sr * n + li];
             } else if ((step & 1u) && sr < spare_nw) {
                 // odd step: the sine-branch normal stored by the even step
-                g = a.spare[sr * n + i];
+                g = a.spare[sr * n + li];
             } else {
                 // time steps 2m, 2m+1 share one Philox block: cosine branch
                 // now, sine branch kept for the next step of this slot
                 double g0, g1;
                 philox_normal2(a.seed, a.slot0 + (unsigned)sr, step >> 1,
-                               (unsigned)i, STREAM_DMC_DIFFUSE, g0, g1);
+                               (unsigned)li, STREAM_DMC_DIFFUSE, g0, g1);
                 g = (step & 1u) ? g1 : g0;
-                if (!(step & 1u) && active) a.spare[sr * n + i] = g1;
+                if (!(step & 1u) && active) a.spare[sr * n + li] = g1;
             }
             // ith_diffusion (qmc_base/jastrow/dmc.py:661-671)
             double zn = z0 + 2 * f0 * a.dt + a.sigma * g;
@@ -524,6 +553,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         }
         z[p] = zz;
     }
+    resort_step<G, P>(z, lab, gl, step, n, m.L, m.half_L);
     double F[P], ei[P], e_next, wf;
     eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, e_next, wf);
     if (!active) return;
@@ -533,6 +563,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         if (i < n) {
             a.cpos[s * n + i] = z[p];
             a.cdrift[s * n + i] = F[p];
+            a.clabel[s * n + i] = (unsigned short)lab[p];
         }
     }
     if (gl == 0) {
@@ -751,6 +782,7 @@ __global__ void est_reduce_kernel(const double *partial, int nblocks, int KC,
 // Gather the yielded ("actual") configurations: confs[s] = parents[ref[s]].
 __global__ void dmc_gather_state_kernel(const double *ppos,
                                         const double *pdrift,
+                                        const unsigned short *plabel,
                                         const long long *ref, long long nw,
                                         int n, double *confs)
 {
@@ -759,17 +791,21 @@ __global__ void dmc_gather_state_kernel(const double *ppos,
     long long s = idx / n;
     int i = (int)(idx % n);
     long long p = ref[s];
-    confs[(s * 2 + 0) * n + i] = ppos[p * n + i];
-    confs[(s * 2 + 1) * n + i] = pdrift[p * n + i];
+    int li = plabel[p * n + i];          // back to the original particle order
+    confs[(s * 2 + 0) * n + li] = ppos[p * n + i];
+    confs[(s * 2 + 1) * n + li] = pdrift[p * n + i];
 }
 
+// Walker record of the population rebalance: pos[N], drift[N], label[N] (as
+// doubles), energy, weight.
 __global__ void pack_walkers_kernel(const double *pos, const double *drift,
+                                    const unsigned short *label,
                                     const double *energy, const double *weight,
                                     long long first, long long count, int n,
                                     double *buf)
 {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int rec = 2 * n + 2;
+    const int rec = 3 * n + 2;
     if (idx >= count * rec) return;
     long long s = idx / rec;
     int j = (int)(idx % rec);
@@ -777,18 +813,20 @@ __global__ void pack_walkers_kernel(const double *pos, const double *drift,
     double v;
     if (j < n) v = pos[src * n + j];
     else if (j < 2 * n) v = drift[src * n + (j - n)];
-    else if (j == 2 * n) v = energy[src];
+    else if (j < 3 * n) v = (double)label[src * n + (j - 2 * n)];
+    else if (j == 3 * n) v = energy[src];
     else v = weight[src];
     buf[idx] = v;
 }
 
 __global__ void unpack_walkers_kernel(double *pos, double *drift,
+                                      unsigned short *label,
                                       double *energy, double *weight,
                                       long long first, long long count, int n,
                                       const double *buf)
 {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int rec = 2 * n + 2;
+    const int rec = 3 * n + 2;
     if (idx >= count * rec) return;
     long long s = idx / rec;
     int j = (int)(idx % rec);
@@ -796,7 +834,8 @@ __global__ void unpack_walkers_kernel(double *pos, double *drift,
     double v = buf[idx];
     if (j < n) pos[dst * n + j] = v;
     else if (j < 2 * n) drift[dst * n + (j - n)] = v;
-    else if (j == 2 * n) energy[dst] = v;
+    else if (j < 3 * n) label[dst * n + (j - 2 * n)] = (unsigned short)v;
+    else if (j == 3 * n) energy[dst] = v;
     else weight[dst] = v;
 }
 
@@ -1079,12 +1118,44 @@ extern "C" int qmc_evaluate(qmc_engine *e, int64_t nconf, const double *pos,
     return rc;
 }
 
+// Sort every configuration by position; label[w][lane] = original particle
+// index held by the lane (see resort_step in qmc_device.h).
+static void sort_rows(const double *pos, size_t W, size_t n,
+                      std::vector<double> &sorted,
+                      std::vector<unsigned short> &label,
+                      const double *extra = nullptr,
+                      std::vector<double> *extra_sorted = nullptr,
+                      size_t pos_stride = 0, size_t extra_stride = 0)
+{
+    if (!pos_stride) pos_stride = n;
+    if (!extra_stride) extra_stride = n;
+    sorted.resize(W * n);
+    label.resize(W * n);
+    if (extra_sorted) extra_sorted->resize(W * n);
+    std::vector<unsigned short> idx(n);
+    for (size_t w = 0; w < W; ++w) {
+        const double *row = pos + w * pos_stride;
+        for (size_t i = 0; i < n; ++i) idx[i] = (unsigned short)i;
+        std::stable_sort(idx.begin(), idx.end(),
+                         [row](unsigned short a, unsigned short b) {
+                             return row[a] < row[b];
+                         });
+        for (size_t i = 0; i < n; ++i) {
+            sorted[w * n + i] = row[idx[i]];
+            label[w * n + i] = idx[i];
+            if (extra_sorted)
+                (*extra_sorted)[w * n + i] = extra[w * extra_stride + idx[i]];
+        }
+    }
+}
+
 // ----------------------------------------------------------------- VMC ----
 struct qmc_vmc {
     qmc_engine *eng = nullptr;
     qmc_vmc_params p;
     long long W = 0;
     double *pos = nullptr, *wf = nullptr, *ecarry = nullptr;
+    unsigned short *label = nullptr;
     double *sum_e = nullptr, *sum_e2 = nullptr;
     long long *n_acc = nullptr;
     double *tape = nullptr;
@@ -1104,8 +1175,8 @@ extern "C" int qmc_vmc_create(qmc_engine *e, const qmc_vmc_params *p,
     v->p = *p;
     v->W = p->num_chains;
     const size_t W = (size_t)v->W, n = (size_t)e->dm.n;
-    if (dev_alloc(&v->pos, W * n) || dev_alloc(&v->wf, W) ||
-        dev_alloc(&v->ecarry, W) || dev_alloc(&v->sum_e, W) ||
+    if (dev_alloc(&v->pos, W * n) || dev_alloc(&v->label, W * n) ||
+        dev_alloc(&v->wf, W) || dev_alloc(&v->ecarry, W) || dev_alloc(&v->sum_e, W) ||
         dev_alloc(&v->sum_e2, W) || dev_alloc(&v->n_acc, W)) {
         delete v;
         return 1;
@@ -1118,7 +1189,7 @@ extern "C" void qmc_vmc_destroy(qmc_vmc *v)
 {
     if (!v) return;
     hipSetDevice(v->eng->device);
-    hipFree(v->pos); hipFree(v->wf); hipFree(v->ecarry);
+    hipFree(v->pos); hipFree(v->label); hipFree(v->wf); hipFree(v->ecarry);
     hipFree(v->sum_e); hipFree(v->sum_e2); hipFree(v->n_acc);
     if (v->tape) hipFree(v->tape);
     delete v;
@@ -1130,7 +1201,12 @@ extern "C" int qmc_vmc_set_state(qmc_vmc *v, const double *pos)
     qmc_engine *e = v->eng;
     HIP_TRY(hipSetDevice(e->device));
     const size_t W = (size_t)v->W, n = (size_t)e->dm.n;
-    HIP_TRY(hipMemcpyAsync(v->pos, pos, W * n * sizeof(double),
+    std::vector<double> sorted;
+    std::vector<unsigned short> label;
+    sort_rows(pos, W, n, sorted, label);
+    HIP_TRY(hipMemcpyAsync(v->pos, sorted.data(), W * n * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(v->label, label.data(), W * n * sizeof(unsigned short),
                            hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemsetAsync(v->ecarry, 0, W * sizeof(double), e->stream));
     int rc = qmc_evaluate_dev(e, v->W, v->pos, v->wf, nullptr, nullptr,
@@ -1150,13 +1226,26 @@ extern "C" int qmc_vmc_get_state(qmc_vmc *v, double *pos, double *wf,
     qmc_engine *e = v->eng;
     HIP_TRY(hipSetDevice(e->device));
     const size_t W = (size_t)v->W, n = (size_t)e->dm.n;
-    if (pos) HIP_TRY(hipMemcpyAsync(pos, v->pos, W * n * sizeof(double),
-                                    hipMemcpyDeviceToHost, e->stream));
+    std::vector<double> lane_pos;
+    std::vector<unsigned short> label;
+    if (pos) {
+        lane_pos.resize(W * n);
+        label.resize(W * n);
+        HIP_TRY(hipMemcpyAsync(lane_pos.data(), v->pos, W * n * sizeof(double),
+                               hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(label.data(), v->label,
+                               W * n * sizeof(unsigned short),
+                               hipMemcpyDeviceToHost, e->stream));
+    }
     if (wf) HIP_TRY(hipMemcpyAsync(wf, v->wf, W * sizeof(double),
                                    hipMemcpyDeviceToHost, e->stream));
     if (ecarry) HIP_TRY(hipMemcpyAsync(ecarry, v->ecarry, W * sizeof(double),
                                        hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (pos)       // back to the caller's particle order
+        for (size_t w = 0; w < W; ++w)
+            for (size_t i = 0; i < n; ++i)
+                pos[w * n + label[w * n + i]] = lane_pos[w * n + i];
     return 0;
 }
 
@@ -1216,7 +1305,7 @@ extern "C" int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_e,
     if (ser_e && dev_alloc(&de, ny * W)) return 1;
     if (ser_stat && dev_alloc(&dst, ny * W)) return 1;
     VmcArgs a;
-    a.pos = v->pos; a.wf = v->wf; a.ecarry = v->ecarry;
+    a.pos = v->pos; a.label = v->label; a.wf = v->wf; a.ecarry = v->ecarry;
     a.sum_e = v->sum_e; a.sum_e2 = v->sum_e2; a.n_acc = v->n_acc;
     a.ser_wf = dwf; a.ser_e = de; a.ser_stat = dst; a.ser_pos = dpos;
     a.tape = v->tape;
@@ -1268,6 +1357,7 @@ struct qmc_dmc {
     int nblocks = 0;
     // two population buffers: [0]/[1] alternate parent / child roles
     double *pos[2] = { nullptr, nullptr }, *drift[2] = { nullptr, nullptr };
+    unsigned short *label[2] = { nullptr, nullptr };
     double *energy[2] = { nullptr, nullptr }, *weight[2] = { nullptr, nullptr };
     int cur = 0;                 // index of the parent buffer
     double *eslot = nullptr;
@@ -1329,6 +1419,7 @@ extern "C" int qmc_dmc_create(qmc_engine *e, const qmc_dmc_params *p,
     int rc = 0;
     for (int b = 0; b < 2 && !rc; ++b) {
         rc |= dev_alloc(&d->pos[b], W * n) || dev_alloc(&d->drift[b], W * n) ||
+              dev_alloc(&d->label[b], W * n) ||
               dev_alloc(&d->energy[b], W) || dev_alloc(&d->weight[b], W);
     }
     rc = rc || dev_alloc(&d->eslot, W) || dev_alloc(&d->spare, W * n) ||
@@ -1349,7 +1440,7 @@ extern "C" void qmc_dmc_destroy(qmc_dmc *d)
     if (!d) return;
     hipSetDevice(d->eng->device);
     for (int b = 0; b < 2; ++b) {
-        hipFree(d->pos[b]); hipFree(d->drift[b]);
+        hipFree(d->pos[b]); hipFree(d->drift[b]); hipFree(d->label[b]);
         hipFree(d->energy[b]); hipFree(d->weight[b]);
     }
     hipFree(d->eslot); hipFree(d->spare); hipFree(d->ref); hipFree(d->count);
@@ -1386,8 +1477,32 @@ static int dmc_reset_ctl(qmc_dmc *d, long long nw, double ref_energy)
     return 0;
 }
 
+static int dmc_zero_population(qmc_dmc *d)
+{
+    qmc_engine *e = d->eng;
+    const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
+    std::vector<unsigned short> ident(W * n);
+    for (size_t s = 0; s < W; ++s)
+        for (size_t i = 0; i < n; ++i) ident[s * n + i] = (unsigned short)i;
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMemsetAsync(d->pos[b], 0, W * n * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->drift[b], 0, W * n * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->energy[b], 0, W * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(d->weight[b], 0, W * sizeof(double), e->stream));
+        HIP_TRY(hipMemcpyAsync(d->label[b], ident.data(),
+                               W * n * sizeof(unsigned short),
+                               hipMemcpyHostToDevice, e->stream));
+    }
+    HIP_TRY(hipMemsetAsync(d->eslot, 0, W * sizeof(double), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// pos: host positions (sorted here) or device positions already in lane order
+// with their labels (label_dev, may be null = identity).
 static int dmc_set_state_impl(qmc_dmc *d, int64_t nw, const double *pos,
-                              bool pos_on_device, int use_ref,
+                              bool pos_on_device,
+                              const unsigned short *label_dev, int use_ref,
                               double ref_energy)
 {
     if (!d || !pos) return fail("qmc_dmc_set_state: null argument");
@@ -1395,17 +1510,27 @@ static int dmc_set_state_impl(qmc_dmc *d, int64_t nw, const double *pos,
         return fail("qmc_dmc_set_state: number of walkers out of range");
     qmc_engine *e = d->eng;
     HIP_TRY(hipSetDevice(e->device));
-    const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(hipMemsetAsync(d->pos[b], 0, W * n * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(d->drift[b], 0, W * n * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(d->energy[b], 0, W * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(d->weight[b], 0, W * sizeof(double), e->stream));
+    const size_t n = (size_t)e->dm.n;
+    if (dmc_zero_population(d)) return 1;
+    if (pos_on_device) {
+        HIP_TRY(hipMemcpyAsync(d->pos[0], pos, (size_t)nw * n * sizeof(double),
+                               hipMemcpyDeviceToDevice, e->stream));
+        if (label_dev)
+            HIP_TRY(hipMemcpyAsync(d->label[0], label_dev,
+                                   (size_t)nw * n * sizeof(unsigned short),
+                                   hipMemcpyDeviceToDevice, e->stream));
+    } else {
+        std::vector<double> sorted;
+        std::vector<unsigned short> label;
+        sort_rows(pos, (size_t)nw, n, sorted, label);
+        HIP_TRY(hipMemcpyAsync(d->pos[0], sorted.data(),
+                               (size_t)nw * n * sizeof(double),
+                               hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d->label[0], label.data(),
+                               (size_t)nw * n * sizeof(unsigned short),
+                               hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    HIP_TRY(hipMemsetAsync(d->eslot, 0, W * sizeof(double), e->stream));
-    HIP_TRY(hipMemcpyAsync(d->pos[0], pos, (size_t)nw * n * sizeof(double),
-                           pos_on_device ? hipMemcpyDeviceToDevice
-                                         : hipMemcpyHostToDevice, e->stream));
     PrepArgs a{ d->pos[0], d->drift[0], d->energy[0], (long long)nw };
     int rc = dispatch_shape<LaunchPrep>(e, a);
     if (rc) return rc;
@@ -1429,14 +1554,26 @@ static int dmc_set_state_impl(qmc_dmc *d, int64_t nw, const double *pos,
 extern "C" int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
                                  int use_ref, double ref_energy)
 {
-    return dmc_set_state_impl(d, nw, pos, false, use_ref, ref_energy);
+    return dmc_set_state_impl(d, nw, pos, false, nullptr, use_ref, ref_energy);
 }
 
 extern "C" int qmc_dmc_set_state_dev(qmc_dmc *d, int64_t nw,
                                      const double *pos_dev, int use_ref,
                                      double ref_energy)
 {
-    return dmc_set_state_impl(d, nw, pos_dev, true, use_ref, ref_energy);
+    return dmc_set_state_impl(d, nw, pos_dev, true, nullptr, use_ref,
+                              ref_energy);
+}
+
+extern "C" int qmc_dmc_set_state_from_vmc(qmc_dmc *d, qmc_vmc *v, int64_t nw,
+                                          int use_ref, double ref_energy)
+{
+    if (!d || !v) return fail("qmc_dmc_set_state_from_vmc: null argument");
+    if (v->eng != d->eng)
+        return fail("qmc_dmc_set_state_from_vmc: ensembles of different engines");
+    if (nw > v->W) return fail("qmc_dmc_set_state_from_vmc: nw > num_chains");
+    return dmc_set_state_impl(d, nw, v->pos, true, v->label, use_ref,
+                              ref_energy);
 }
 
 extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
@@ -1453,21 +1590,17 @@ extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
     qmc_engine *e = d->eng;
     HIP_TRY(hipSetDevice(e->device));
     const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
-    std::vector<double> hp((size_t)nw * n), hd((size_t)nw * n);
-    for (size_t s = 0; s < (size_t)nw; ++s) {
-        memcpy(&hp[s * n], confs + (s * 2 + 0) * n, n * sizeof(double));
-        memcpy(&hd[s * n], confs + (s * 2 + 1) * n, n * sizeof(double));
-    }
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(hipMemsetAsync(d->pos[b], 0, W * n * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(d->drift[b], 0, W * n * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(d->energy[b], 0, W * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(d->weight[b], 0, W * sizeof(double), e->stream));
-    }
-    HIP_TRY(hipMemsetAsync(d->eslot, 0, W * sizeof(double), e->stream));
+    // confs[s] = (pos row, drift row): sort by position, carry the drift along
+    std::vector<double> hp, hd;
+    std::vector<unsigned short> label;
+    sort_rows(confs, (size_t)nw, n, hp, label, confs + n, &hd, 2 * n, 2 * n);
+    if (dmc_zero_population(d)) return 1;
     HIP_TRY(hipMemcpyAsync(d->pos[0], hp.data(), hp.size() * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d->drift[0], hd.data(), hd.size() * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d->label[0], label.data(),
+                           label.size() * sizeof(unsigned short),
                            hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d->energy[0], energy, (size_t)nw * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
@@ -1543,6 +1676,7 @@ static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev)
     EvolveArgs a;
     a.ppos = d->pos[par]; a.pdrift = d->drift[par]; a.penergy = d->energy[par];
     a.cpos = d->pos[chi]; a.cdrift = d->drift[chi];
+    a.plabel = d->label[par]; a.clabel = d->label[chi];
     a.cenergy = d->energy[chi]; a.cweight = d->weight[chi];
     a.eslot = d->eslot; a.ref = d->ref; a.ctl = d->ctl; a.g_tape = gt;
     a.spare = d->spare;
@@ -1832,21 +1966,25 @@ extern "C" int qmc_dmc_get_state(qmc_dmc *d, double *confs, double *energy,
             hipLaunchKernelGGL(dmc_gather_state_kernel,
                                dim3((unsigned)((tot + 255) / 256)), dim3(256),
                                0, e->stream, d->pos[par], d->drift[par],
-                               d->ref, nw, (int)n, tmp);
+                               d->label[par], d->ref, nw, (int)n, tmp);
             HIP_TRY(hipMemcpyAsync(confs, tmp, (size_t)nw * 2 * n * 8,
                                    hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
             hipFree(tmp);
         } else {
             std::vector<double> hp((size_t)nw * n), hd((size_t)nw * n);
+            std::vector<unsigned short> hl((size_t)nw * n);
             HIP_TRY(hipMemcpy(hp.data(), d->pos[d->cur], hp.size() * 8,
                               hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(hd.data(), d->drift[d->cur], hd.size() * 8,
                               hipMemcpyDeviceToHost));
-            for (size_t s = 0; s < (size_t)nw; ++s) {
-                memcpy(confs + (s * 2 + 0) * n, &hp[s * n], n * 8);
-                memcpy(confs + (s * 2 + 1) * n, &hd[s * n], n * 8);
-            }
+            HIP_TRY(hipMemcpy(hl.data(), d->label[d->cur], hl.size() * 2,
+                              hipMemcpyDeviceToHost));
+            for (size_t s = 0; s < (size_t)nw; ++s)
+                for (size_t i = 0; i < n; ++i) {
+                    confs[(s * 2 + 0) * n + hl[s * n + i]] = hp[s * n + i];
+                    confs[(s * 2 + 1) * n + hl[s * n + i]] = hd[s * n + i];
+                }
         }
     }
     if (energy) {
@@ -1882,10 +2020,11 @@ extern "C" int qmc_dmc_export_walkers(qmc_dmc *d, int64_t first, int64_t count,
     qmc_engine *e = d->eng;
     HIP_TRY(hipSetDevice(e->device));
     const int n = e->dm.n;
-    long long tot = count * (long long)(2 * n + 2);
+    long long tot = count * (long long)(3 * n + 2);
     hipLaunchKernelGGL(pack_walkers_kernel, dim3((unsigned)((tot + 255) / 256)),
                        dim3(256), 0, e->stream, d->pos[d->cur],
-                       d->drift[d->cur], d->energy[d->cur], d->weight[d->cur],
+                       d->drift[d->cur], d->label[d->cur], d->energy[d->cur],
+                       d->weight[d->cur],
                        (long long)first, (long long)count, n, buf_dev);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1920,11 +2059,12 @@ extern "C" int qmc_dmc_import_walkers(qmc_dmc *d, int64_t count,
         return fail("qmc_dmc_import_walkers: population would exceed "
                     "max_num_walkers");
     const int n = e->dm.n;
-    long long tot = count * (long long)(2 * n + 2);
+    long long tot = count * (long long)(3 * n + 2);
     hipLaunchKernelGGL(unpack_walkers_kernel,
                        dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                        e->stream, d->pos[d->cur], d->drift[d->cur],
-                       d->energy[d->cur], d->weight[d->cur], (long long)nw,
+                       d->label[d->cur], d->energy[d->cur], d->weight[d->cur],
+                       (long long)nw,
                        (long long)count, n, buf_dev);
     HIP_TRY(hipGetLastError());
     return dmc_set_prev_nw(d, nw + count);

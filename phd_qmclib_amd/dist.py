@@ -17,7 +17,7 @@ What is exchanged, and why only that:
 * Local populations random-walk apart, so every `rebalance_every` steps the
   ranks all-gather their counts, derive the same greedy plan (ranks above the
   mean send their tail walkers to ranks below it) and move whole walker
-  records (pos, drift, energy, weight: 2N+2 doubles) with point-to-point
+  records (pos, drift, lane labels, energy, weight: 3N+2 doubles) with point-to-point
   send/recv -- single hop on the fully connected xGMI mesh.
 
 The reference has no distributed path at all; its global cap
@@ -155,7 +155,7 @@ class DistributedDmc:
                 (max(counts) - min(counts)) <= self.imbalance_tol * mean:
             return 0
         plan = rebalance_plan(counts)
-        rec = 2 * self.n + 2
+        rec = 3 * self.n + 2
         moved = 0
         nw = counts[self.rank]
         ops, bufs = [], []

@@ -279,9 +279,8 @@ class DmcEnsemble:
         if nw > vmc.num_chains:
             raise ValueError('more walkers requested than chains')
         self.engine.sync()
-        pos_ptr, _ = vmc.state_dev()
-        check(self._lib.qmc_dmc_set_state_dev(
-            self._h, nw, pos_ptr, int(ref_energy is not None),
+        check(self._lib.qmc_dmc_set_state_from_vmc(
+            self._h, vmc._h, nw, int(ref_energy is not None),
             float(ref_energy if ref_energy is not None else 0.0)))
 
     def set_full_state(self, confs, energy, weight, ref_energy: float,

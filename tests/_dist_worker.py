@@ -68,23 +68,24 @@ class OracleShard:
 
     def export_walkers(self, first, count, buf_ptr):
         confs, en, wt = self._pop()
-        rec = 2 * self.n + 2
+        rec = 3 * self.n + 2
         out = self._view(buf_ptr, (count, rec))
         out[:, :self.n] = confs[first:first + count, 0]
         out[:, self.n:2 * self.n] = confs[first:first + count, 1]
-        out[:, 2 * self.n] = en[first:first + count]
-        out[:, 2 * self.n + 1] = wt[first:first + count]
+        out[:, 2 * self.n:3 * self.n] = np.arange(self.n)     # lane labels
+        out[:, 3 * self.n] = en[first:first + count]
+        out[:, 3 * self.n + 1] = wt[first:first + count]
 
     def import_walkers(self, count, buf_ptr):
         confs, en, wt = self._pop()
-        rec = 2 * self.n + 2
+        rec = 3 * self.n + 2
         src = self._view(buf_ptr, (count, rec))
         nw = self.num_walkers()
         assert nw + count <= self.maxw
         confs[nw:nw + count, 0] = src[:, :self.n]
         confs[nw:nw + count, 1] = src[:, self.n:2 * self.n]
-        en[nw:nw + count] = src[:, 2 * self.n]
-        wt[nw:nw + count] = src[:, 2 * self.n + 1]
+        en[nw:nw + count] = src[:, 3 * self.n]
+        wt[nw:nw + count] = src[:, 3 * self.n + 1]
         self.ens.st.prev_num_walkers = nw + count
 
     def truncate(self, new_nw):
