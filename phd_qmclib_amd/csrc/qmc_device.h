@@ -385,13 +385,14 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     do {                                                                      \
         Qall = fma(q, q, Qall);                                               \
         if (!WAVE_COUNT) ++npair;                                             \
+        /* prodL runs over ALL pairs (no else branch, no second compare);   \
+           the short factors are divided out once at the end */             \
+        if (WF) prodL *= Y;          /* sign dropped at the end */            \
         if (isshort) {                                                        \
             asm volatile("");   /* exec-masked, not selects */                \
             Qs = fma(q, q, Qs);                                               \
             if (!WAVE_COUNT) ++nshort;                                        \
             if (WF) prodS *= Y;                                               \
-        } else {                                                              \
-            if (WF) { asm volatile(""); prodL *= fabs(Y); }                   \
         }                                                                     \
     } while (0)
 #define QMC_PAIR_KIN(q, isshort)                                              \
@@ -471,6 +472,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 QMC_FOLD(prodL, expL);                                        \
             }                                                                 \
         }
+        // (kept rolled: unrolled, the scheduler hoists the LDS reads of every
+        // copy and the kernel loses half its occupancy -- measured -8 %)
         for (int k = 1; k < G / 2; ++k)
             QMC_KSTEP(k, false)
         QMC_KSTEP(G / 2, true)
@@ -511,8 +514,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     }
     if (WF) {
         const double LN2 = 0.693147180559945309417;
-        double lw = log_pos(prod1 * prodS) + m.beta * log_pos(prodL) +
-                    LN2 * ((double)expS + m.beta * (double)expL);
+        // prodL holds every pair's |Y|, prodS the short ones (cos > 0):
+        // long product = prodL / prodS (mantissas; exponents kept apart)
+        double lw = log_pos(prod1 * prodS) +
+                    m.beta * log_pos(fabs(fast_div(prodL, prodS))) +
+                    LN2 * ((double)expS + m.beta * (double)(expL - expS));
         if (!WAVE_COUNT) lw += (double)nshort * m.log_am;
         logwf = group_sum<G>(lw);
         if (WAVE_COUNT) logwf += (double)ns_wave * m.log_am;

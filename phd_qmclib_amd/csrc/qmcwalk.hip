@@ -250,22 +250,36 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             philox_uniform2(a.seed, slot, a.step, 0u, STREAM_VMC_ACCEPT, ua,
                             u1);
         } else {
-            // exactly one lane of the group holds particle 0 (ua >= 0 there)
-            double best = -1.0;
+            // exactly one lane of the group holds particle 0 (ua >= 0 there):
+            // find it with a ballot and read its value
+            double mine = uas[0];
 #pragma unroll
-            for (int p = 0; p < P; ++p) best = fmax(best, uas[p]);
-#pragma unroll
-            for (int msk = 1; msk < G; msk <<= 1)
-                best = fmax(best, __shfl_xor(best, msk, 64));
-            ua = best;
+            for (int p = 1; p < P; ++p) mine = (uas[p] >= 0.0) ? uas[p] : mine;
+            const unsigned long long bal = __ballot(mine >= 0.0);
+            if (G == 64) {
+                const int src = __builtin_amdgcn_readfirstlane(
+                    (int)__ffsll((long long)bal) - 1) & 63;
+                int lo = __double2loint(mine), hi = __double2hiint(mine);
+                lo = __builtin_amdgcn_readlane(lo, src);
+                hi = __builtin_amdgcn_readlane(hi, src);
+                ua = __hiloint2double(hi, lo);
+            } else {
+                const int base = (threadIdx.x & 63) - gl;
+                const unsigned long long grp_bits =
+                    (bal >> base) & ((1ull << (G & 63)) - 1ull);
+                const int src = base + ((__ffsll((long long)grp_bits) - 1) & (G - 1));
+                ua = __shfl(mine, src, 64);
+            }
         }
     }
     if (!active) return;
     double wf_cur = a.wf[w];
     double e_cur = a.ecarry[w];
     // Metropolis test (qmc_base/vmc.py:636)
-    const bool acc = forced || ua <= 0.0 ||
-                     (wf_new > 0.5 * log_pos(ua) + wf_cur);
+    // log(u) <= 0: an uphill move needs no logarithm (wave-uniform when one
+    // wavefront owns one chain)
+    bool acc = forced || ua <= 0.0 || wf_new > wf_cur;
+    if (!acc) acc = wf_new > 0.5 * log_pos(ua) + wf_cur;
     if (acc) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
