@@ -24,6 +24,7 @@
 #ifndef QMCWALK_H
 #define QMCWALK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -123,6 +124,16 @@ int qmc_evaluate(qmc_engine *eng, int64_t nconf, const double *pos,
 int qmc_evaluate_dev(qmc_engine *eng, int64_t nconf, const double *pos_dev,
                      double *wf_dev, double *energy_dev, double *ith_dev,
                      double *drift_dev);
+
+/* Plain device buffers, so that a configuration set can stay resident across
+ * many qmc_evaluate_dev calls with different engines: the correlated-sampling
+ * optimiser re-evaluates wf_abs_log / energy of one fixed set for every trial
+ * value of the variational parameter (mrbp_qmc/model.py:818-942,
+ * qmc_base/jastrow/model.py:1125-1206).  upload/download are synchronous. */
+int qmc_buffer_alloc(int device, size_t bytes, void **out);
+int qmc_buffer_free(void *buf);
+int qmc_buffer_upload(void *dst_dev, const void *src_host, size_t bytes);
+int qmc_buffer_download(void *dst_host, const void *src_dev, size_t bytes);
 
 /* ---- VMC ensemble of independent Metropolis chains -------------------- */
 /* vmc.Sampling + core_funcs.states_generator/blocks (qmc_base/vmc.py:557-648,

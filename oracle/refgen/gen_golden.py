@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY (see harness.py).  Run in the build container:
 
     MPLBACKEND=Agg /opt/conda/bin/python3.9 oracle/refgen/gen_golden.py [which ...]
 
-`which` in {params, kernels, vmc_tape, dmc_tape, reblock, stats}; default all.
+`which` in {params, kernels, vmc_tape, dmc_tape, reblock, stats, dmc_est,
+wf_opt}; default all.
 Every output is *data* (inputs + the reference's outputs); no reference code
 is stored.  numpy seeds are fixed so a re-run reproduces the files.
 """
@@ -461,7 +462,50 @@ def gen_dmc_est():
     np.savez_compressed(os.path.join(OUT, 'dmc_est.npz'), **out)
 
 
-ALL = dict(dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
+def gen_wf_opt():
+    """Correlated-sampling variance of the local energy:
+    the reference's CSWFOptimizer.principal_function on a fixed configuration
+    set, for a scan of tbf_contact_cutoff values."""
+    out = {}
+    for tag in ('box16', 'deep16', 'free16'):
+        spec = mrbp_qmc.Spec(**SPECS[tag])
+        rng = np.random.RandomState(97)
+        n, L = spec.boson_number, spec.supercell_size
+        nconf = 96
+        confs = np.zeros((nconf, 2, n))
+        confs[:, 0, :] = L * rng.random_sample((nconf, n))
+        # a few regular configurations with jitter
+        reg = (np.arange(n) + 0.25) * L / n
+        confs[:8, 0, :] = (reg + 0.05 * rng.standard_normal((8, n))) % L
+        args = spec.cfc_spec
+        ini_wf = np.array([core.wf_abs_log(c, args.model_params,
+                                           args.obf_params, args.tbf_params)
+                           for c in confs])
+        opt = mrbp_qmc.CSWFOptimizer(spec, confs, ini_wf, num_workers=1)
+        (lo, hi), = opt.principal_function_bounds
+        cuts = np.linspace(lo, hi, 7)
+        cuts[3] = spec.tbf_contact_cutoff
+        var = np.array([opt.principal_function(c) for c in cuts])
+        wf_en = [opt.wf_abs_log_and_energy_set(opt.update_spec(c).cfc_spec)
+                 for c in cuts]
+        out[tag + '/pos'] = confs[:, 0, :].copy()
+        out[tag + '/ini_wf'] = ini_wf
+        out[tag + '/bounds'] = np.array([lo, hi])
+        out[tag + '/cutoffs'] = cuts
+        out[tag + '/variance'] = var
+        out[tag + '/wf_set'] = np.array([w for w, _ in wf_en])
+        out[tag + '/energy_set'] = np.array([e for _, e in wf_en])
+        print('wf_opt', tag, cuts, var)
+    # weighed_variance on plain arrays
+    rng = np.random.RandomState(5)
+    wl, en = rng.standard_normal(50) * 3, 10 + rng.standard_normal(50)
+    out['wv/weights_log'] = wl
+    out['wv/energy'] = en
+    out['wv/value'] = np.array(mrbp_qmc.CSWFOptimizer.weighed_variance(wl, en))
+    np.savez_compressed(os.path.join(OUT, 'wf_opt.npz'), **out)
+
+
+ALL = dict(wf_opt=gen_wf_opt, dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
            dmc_tape=gen_dmc_tape, reblock=gen_reblock, stats=gen_stats)
 
 if __name__ == '__main__':

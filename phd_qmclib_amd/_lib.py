@@ -73,6 +73,10 @@ SIGNATURES = {
     'qmc_engine_timer_stop': (C.c_int, [_vp, C.POINTER(C.c_float)]),
     'qmc_evaluate': (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp, _dp, _dp]),
     'qmc_evaluate_dev': (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    'qmc_buffer_alloc': (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),
+    'qmc_buffer_free': (C.c_int, [_vp]),
+    'qmc_buffer_upload': (C.c_int, [_vp, _vp, C.c_size_t]),
+    'qmc_buffer_download': (C.c_int, [_vp, _vp, C.c_size_t]),
     'qmc_vmc_create': (C.c_int, [_vp, C.POINTER(VmcParams), C.POINTER(_vp)]),
     'qmc_vmc_destroy': (None, [_vp]),
     'qmc_vmc_set_state': (C.c_int, [_vp, _dp]),

@@ -47,7 +47,8 @@ struct DevModel {
     double m_k2cphi;       // -k2 cos(k2 r_off)
     double k2sphi;         //  k2 sin(k2 r_off)
     double cphi, sphi;     // cos/sin(k2 r_off)
-    double cth, sth;       // cos/sin(k2 L)
+    double cth, sth;       // cos(k2 L), |sin(k2 L)|
+    int sth_sign;          // sign bit of sin(k2 L) (0 or 0x80000000)
     double sin_rm;         // sin(pi rm / L)
     double a_long, b_long; // (pi/L) beta, (pi/L)^2 beta
     double inv_beta;       // 1 / beta
@@ -223,6 +224,7 @@ struct PairConsts {
     double sin_rm, cth, m_k2cphi, sphi, cphi;
     double v_sth, v_k2sphi;       // VGPR-resident
     double half_L, rm, L_minus_rm;
+    int sth_sign;
 };
 
 __device__ __forceinline__ PairConsts load_pair_consts(const DevModel &m)
@@ -232,6 +234,7 @@ __device__ __forceinline__ PairConsts load_pair_consts(const DevModel &m)
     c.sphi = m.sphi; c.cphi = m.cphi;
     c.half_L = m.half_L; c.rm = m.rm; c.L_minus_rm = m.L_minus_rm;
     c.v_sth = m.sth; c.v_k2sphi = m.k2sphi;
+    c.sth_sign = m.sth_sign;
     asm volatile("" : "+v"(c.v_sth), "+v"(c.v_k2sphi));
     return c;
 }
@@ -272,7 +275,11 @@ __device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
             // v_cndmask on top of the arithmetic
             asm volatile("");
             // min image d = D - sgn(D) L; sgn(D) = sgn(S)
+            // t = sin(k2 L) sgn(S): copysign on |sin(k2 L)|, then the sign of
+            // sin(k2 L) itself (k2 L is any angle) xor-ed into the high word
             double t = __builtin_copysign(m.v_sth, S);
+            t = __hiloint2double(__double2hiint(t) ^ m.sth_sign,
+                                 __double2loint(t));
             double ct, st;
             const double cth = m.cth;
             // in place, exactly four instructions (the compiler's two-address

@@ -986,7 +986,8 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.k2sphi = d.k2 * d.sphi;
     double th = p.param_k2 * d.L;
     d.cth = cos(th);
-    d.sth = sin(th);
+    d.sth = fabs(sin(th));
+    d.sth_sign = sin(th) < 0.0 ? (int)0x80000000u : 0;
     d.sin_rm = (d.rm >= d.half_L) ? 1.0 : sin(QMC_PI * d.rm / d.L);
     // sin(pi r / L) is flat near r = L/2: classify from positions there
     d.zclass = d.rm > 0.45 * d.L;
@@ -1030,6 +1031,16 @@ extern "C" int qmc_engine_create(const qmc_model_params *model, int device,
         return fail("qmc_engine_create: boson_number must be in [1, 512]");
     }
     build_dev_model(*model, e->dm);
+    // domain of the short-range kernel (qmc_device.h pair_core): the matching
+    // conditions of mrbp_qmc/model.py:340-392 give phi = k2 r_off in (0, pi/2)
+    // and k2 rm in (0, pi/2) for every repulsive model
+    if (!e->dm.is_ideal &&
+        (e->dm.sphi < 0.0 || e->dm.cphi < 0.0 ||
+         e->dm.k2 * e->dm.rm >= 0.5 * QMC_PI || e->dm.k2 <= 0.0)) {
+        delete e;
+        return fail("qmc_engine_create: two-body parameters outside the "
+                    "model's domain (need 0 < k2 rm < pi/2, 0 <= k2 r_off <= pi/2)");
+    }
     HIP_TRY(hipSetDevice(device));
     if (stream) {
         e->stream = (hipStream_t)stream;
@@ -1100,6 +1111,39 @@ extern "C" int qmc_evaluate_dev(qmc_engine *e, int64_t nconf,
     HIP_TRY(hipSetDevice(e->device));
     EvalArgs a{ pos, wf, energy, ith, drift, (long long)nconf };
     return dispatch_shape<LaunchEval>(e, a);
+}
+
+// Plain device buffers (configuration sets kept resident across
+// qmc_evaluate_dev calls by callers without a device-memory library).
+extern "C" int qmc_buffer_alloc(int device, size_t bytes, void **out)
+{
+    if (!out || !bytes) return fail("qmc_buffer_alloc: null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes));
+    return 0;
+}
+
+extern "C" int qmc_buffer_free(void *buf)
+{
+    if (buf) HIP_TRY(hipFree(buf));
+    return 0;
+}
+
+extern "C" int qmc_buffer_upload(void *dst_dev, const void *src_host,
+                                 size_t bytes)
+{
+    if (!dst_dev || !src_host) return fail("qmc_buffer_upload: null argument");
+    HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int qmc_buffer_download(void *dst_host, const void *src_dev,
+                                   size_t bytes)
+{
+    if (!dst_host || !src_dev)
+        return fail("qmc_buffer_download: null argument");
+    HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int qmc_evaluate(qmc_engine *e, int64_t nconf, const double *pos,

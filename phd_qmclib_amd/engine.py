@@ -13,6 +13,7 @@ from ._lib import (DmcEstParams, DmcParams, ModelParams, QmcError, VmcParams,
                    _i64p, _u64p, _u8p)
 
 __all__ = ['ModelEngine', 'VmcEnsemble', 'DmcEnsemble', 'EvalResult',
+           'DeviceBuffer',
            'model_params_struct', 'QmcError']
 
 
@@ -54,6 +55,48 @@ def _current_device():
     except Exception:     # torch missing or no GPU runtime
         pass
     return 0
+
+
+class DeviceBuffer:
+    """A plain fp64 array in HBM (qmc_buffer_*): inputs / outputs of
+    `ModelEngine.evaluate_dev` that stay resident across calls."""
+
+    def __init__(self, shape, device: t.Optional[int] = None):
+        self._lib = _lib.load()
+        self.shape = tuple(int(x) for x in np.atleast_1d(shape))
+        self.nbytes = int(np.prod(self.shape)) * 8
+        self.device = _current_device() if device is None else int(device)
+        h = C.c_void_p()
+        check(self._lib.qmc_buffer_alloc(self.device, self.nbytes, C.byref(h)))
+        self._h = h
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        if a.shape != self.shape:
+            raise ValueError(f'expected shape {self.shape}, got {a.shape}')
+        check(self._lib.qmc_buffer_upload(self._h, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self):
+        out = np.empty(self.shape)
+        check(self._lib.qmc_buffer_download(out.ctypes.data, self._h,
+                                            out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.qmc_buffer_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ModelEngine:

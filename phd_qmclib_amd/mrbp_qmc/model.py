@@ -19,7 +19,7 @@ from scipy.optimize import brentq
 
 from .. import ideal
 
-__all__ = ['CFCSpec', 'OBFParams', 'Params', 'Spec', 'TBFParams',
+__all__ = ['CSWFOptimizer', 'CFCSpec', 'OBFParams', 'Params', 'Spec', 'TBFParams',
            'SysConfSlot', 'SysConfDistType', 'DIST_RAND', 'DIST_REGULAR',
            'core_funcs']
 
@@ -336,3 +336,117 @@ class _CoreFuncs:
 
 
 core_funcs = _CoreFuncs()
+
+
+class CSWFOptimizer:
+    """Correlated-sampling optimisation of the trial wave function: finds the
+    `tbf_contact_cutoff` that minimises the (re-weighted) variance of the
+    local energy over a fixed set of configurations (reference:
+    mrbp_qmc/model.py:818-942, qmc_base/jastrow/model.py:1125-1206).
+
+    The configuration set is uploaded to HBM once; every trial value of the
+    variational parameter is one batched launch of the pair-sum kernel
+    (wf_abs_log + energy of all configurations) with that parameter set's
+    engine.  The reference's `use_threads` / `num_workers` (dask scheduler
+    knobs) are accepted and ignored."""
+
+    def __init__(self, spec: Spec, sys_conf_set, ini_wf_abs_log_set,
+                 ref_energy: t.Optional[float] = None,
+                 use_threads: bool = True,
+                 num_workers: t.Optional[int] = None,
+                 verbose: bool = False):
+        self.spec = spec
+        self.sys_conf_set = np.asarray(sys_conf_set, dtype=np.float64)
+        self.ini_wf_abs_log_set = np.asarray(ini_wf_abs_log_set,
+                                             dtype=np.float64)
+        self.ref_energy = ref_energy
+        self.use_threads = use_threads
+        self.num_workers = num_workers
+        self.verbose = verbose
+        scs = self.sys_conf_set
+        n = spec.boson_number
+        if scs.ndim == 3 and scs.shape[1:] == (len(SysConfSlot), n):
+            pos = scs[:, SysConfSlot.pos, :]
+        elif scs.ndim == 2 and scs.shape[1] == n:
+            pos = scs
+        else:
+            raise ValueError('sys_conf_set must have shape (nconf, 2, '
+                             'boson_number) or (nconf, boson_number)')
+        if self.ini_wf_abs_log_set.shape != (pos.shape[0],):
+            raise ValueError('ini_wf_abs_log_set must have one value per '
+                             'configuration')
+        # wf_abs_log and energy are symmetric in the particles: sorted
+        # positions make the short-range branch of the kernel wave-uniform
+        self._pos = np.sort(pos, axis=1)
+        self._dev = None
+
+    # -- device residency ---------------------------------------------
+    def _buffers(self):
+        if self._dev is None:
+            from ..engine import DeviceBuffer
+            W, n = self._pos.shape
+            self._dev = (DeviceBuffer((W, n)).upload(self._pos),
+                         DeviceBuffer((W,)), DeviceBuffer((W,)))
+        return self._dev
+
+    def close(self):
+        if self._dev is not None:
+            for b in self._dev:
+                b.close()
+            self._dev = None
+
+    def update_spec(self, tbf_contact_cutoff: float):
+        """The model spec with a new value of the variational parameter."""
+        return attr.evolve(self.spec,
+                           tbf_contact_cutoff=float(tbf_contact_cutoff))
+
+    def wf_abs_log_and_energy_set(self, cfc_spec: CFCSpec):
+        """wf_abs_log and local energy of every configuration of the set
+        under the given parameters."""
+        from ..engine import ModelEngine
+        pos_d, wf_d, en_d = self._buffers()
+        eng = ModelEngine(cfc_spec, device=pos_d.device)
+        try:
+            eng.evaluate_dev(self._pos.shape[0], pos_d.ptr, wf_d.ptr,
+                             en_d.ptr)
+            eng.sync()
+        finally:
+            eng.close()
+        return wf_d.download(), en_d.download()
+
+    @staticmethod
+    def weighed_variance(weights_log_set, energy_set, ref_energy=None):
+        """Weighed variance of the energies
+        (qmc_base/jastrow/model.py:1146-1164; the reference ignores
+        `ref_energy` and uses the weighed mean)."""
+        rel_weights = np.exp(weights_log_set - weights_log_set.max())
+        weight_sum = rel_weights.sum()
+        ref_energy = (rel_weights * energy_set).sum() / weight_sum
+        e_diff = rel_weights * (energy_set - ref_energy) ** 2
+        return e_diff.sum() / weight_sum
+
+    def principal_function(self, tbf_contact_cutoff):
+        """The weighed variance of the local energy for a trial cutoff."""
+        cutoff = float(np.ravel(tbf_contact_cutoff)[0])
+        cfc_spec = self.update_spec(cutoff).cfc_spec
+        wf_set, energy_set = self.wf_abs_log_and_energy_set(cfc_spec)
+        weights_log_set = 2 * (wf_set - self.ini_wf_abs_log_set)
+        return self.weighed_variance(weights_log_set, energy_set)
+
+    @property
+    def principal_function_bounds(self):
+        sc_size = self.spec.supercell_size
+        return [(5e-2, (0.5 - 5e-3) * sc_size)]
+
+    def exec(self, seed=None):
+        """Runs the minimisation (scipy `differential_evolution`, as the
+        reference) and returns the spec with the optimal cutoff."""
+        from scipy.optimize import differential_evolution
+        try:
+            res = differential_evolution(self.principal_function,
+                                         bounds=self.principal_function_bounds,
+                                         disp=self.verbose, seed=seed)
+        finally:
+            self.close()
+        opt_cutoff, = res.x
+        return self.update_spec(opt_cutoff)
