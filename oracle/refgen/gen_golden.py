@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY (see harness.py).  Run in the build container:
     MPLBACKEND=Agg /opt/conda/bin/python3.9 oracle/refgen/gen_golden.py [which ...]
 
 `which` in {params, kernels, vmc_tape, dmc_tape, reblock, stats, dmc_est,
-wf_opt}; default all.
+wf_opt, sweep}; default all.
 Every output is *data* (inputs + the reference's outputs); no reference code
 is stored.  numpy seeds are fixed so a re-run reproduces the files.
 """
@@ -505,7 +505,57 @@ def gen_wf_opt():
     np.savez_compressed(os.path.join(OUT, 'wf_opt.npz'), **out)
 
 
-ALL = dict(wf_opt=gen_wf_opt, dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
+def gen_sweep():
+    """Random model specs (depth, ratio, coupling, filling, cutoff, defects)
+    with a few configurations each: parameter derivation and the kernel
+    functions away from the r_m = L/4 unit-filling boxes."""
+    rng = np.random.RandomState(20260)
+    recs, k = [], 0
+    out = {}
+    while len(recs) < 36:
+        n = int(rng.randint(3, 41))
+        L = float(np.round(n * rng.uniform(0.6, 2.2), 3))
+        kw = dict(lattice_depth=float(np.round(rng.choice(
+                      [0.0, rng.uniform(0.5, 20), rng.uniform(20, 250)]), 4)),
+                  lattice_ratio=float(np.round(rng.uniform(0.15, 4.0), 4)),
+                  interaction_strength=float(np.round(
+                      10 ** rng.uniform(-1.5, 2.0), 5)),
+                  boson_number=n, supercell_size=L,
+                  tbf_contact_cutoff=float(np.round(
+                      L * rng.uniform(0.004, 0.4949), 5)))
+        if rng.random_sample() < 0.3:
+            cells = int(np.ceil(L))
+            divs = [d for d in range(1, cells + 1) if cells % d == 0]
+            kw['num_defects'] = int(rng.choice(divs))
+            kw['defect_magnitude'] = float(np.round(rng.uniform(0, 60), 3))
+        try:
+            spec = mrbp_qmc.Spec(**kw)
+            args = spec.cfc_spec
+        except (ValueError, ZeroDivisionError, RuntimeError) as exc:
+            print('sweep skip', kw, type(exc).__name__)
+            continue
+        confs = make_confs(spec, rng, num_random=3) if n >= 12 else \
+            np.array([np.vstack([L * rng.random_sample(n), np.zeros(n)])
+                      for _ in range(5)])
+        wf = [core.wf_abs_log(c, *args) for c in confs]
+        en = [core.energy(c, *args) for c in confs]
+        ie = [[core.ith_energy_and_drift(i, c, *args) for i in range(n)]
+              for c in confs]
+        tag = 'sweep%02d' % len(recs)
+        recs.append(dict(tag=tag, spec=kw, params=jsonable(spec.params),
+                         obf_params=jsonable(spec.obf_params),
+                         tbf_params=jsonable(spec.tbf_params)))
+        out[tag + '/pos'] = confs[:, 0, :].copy()
+        out[tag + '/wf_abs_log'] = np.array(wf)
+        out[tag + '/energy'] = np.array(en)
+        out[tag + '/ith'] = np.array(ie)      # [conf, i, (energy, drift)]
+        print(tag, kw, wf[0], en[0])
+    with open(os.path.join(OUT, 'sweep.json'), 'w') as fp:
+        json.dump(recs, fp, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, 'sweep.npz'), **out)
+
+
+ALL = dict(sweep=gen_sweep, wf_opt=gen_wf_opt, dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
            dmc_tape=gen_dmc_tape, reblock=gen_reblock, stats=gen_stats)
 
 if __name__ == '__main__':
