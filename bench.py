@@ -54,6 +54,9 @@ def main():
     ap.add_argument('--dmc-walkers', type=int, default=1 << 18)
     ap.add_argument('--no-dmc', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--dmc-dist', action='store_true',
+                    help='also time ONE DMC population sharded over all ranks '
+                         '(per-step RCCL all-reduce of (E_t, W_t) + rebalance)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
 
@@ -211,8 +214,52 @@ def main():
         }
         d.close()
 
-    # ---------------- CPU baseline (oracle, rank 0) ----------------
-    if not args.no_cpu and rank == 0:
+    # ---------------- DMC, one population over all ranks (opt-in) ---------
+    if args.dmc_dist:
+        from phd_qmclib_amd.dist import DistributedDmc
+        per_rank = args.dmc_walkers
+        target = per_rank * world
+        cap = ((per_rank * 512 // 480) + 255) // 256 * 256
+        pos0, _, _ = vmc.get_state()
+        d = DmcEnsemble(eng, 6.25e-4, cap, target, 0.5, rng_seed=1,
+                        slot0=rank * cap, external_reduce=True)
+        d.set_state(pos0[:per_rank])
+        # every rank must start from the same E_ref: the global mean energy
+        er = torch.tensor([d.get_state().ref_energy], dtype=torch.float64,
+                          device='cuda')
+        if use_pg:
+            dist.all_reduce(er)
+        d.set_state(pos0[:per_rank], ref_energy=float(er.item()) / world)
+        del pos0
+        dd = DistributedDmc(d, n, torch.device('cuda', local_rank),
+                            rebalance_every=32)
+        dd.run_block(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        ser = dd.run_block(args.steps)
+        barrier()
+        ddt = time.perf_counter() - t0
+        loc = torch.tensor([float(ser.num_walkers.sum()), ddt],
+                           dtype=torch.float64, device='cuda')
+        tmx = loc[1:].clone()
+        if use_pg:
+            dist.all_reduce(loc[:1])
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            out['extra']['dmc_dist'] = {
+                'workload': f'mrbp_qmc DMC, N={n}, ONE population of target '
+                            f'{target} walkers sharded over {world} rank(s), '
+                            f'16-byte all-reduce per step, rebalance every 32',
+                'walker_steps_per_s': float(loc[0].item()) / float(tmx.item()),
+                'ms_per_step': float(tmx.item()) / args.steps * 1e3,
+                'walkers_moved_rank0': dd.walkers_moved,
+                'energy_per_particle':
+                    float(ser.energy.sum() / ser.weight.sum() / n),
+            }
+        d.close()
+
+    # ---------------- CPU baseline (oracle, rank 0, N = 1 only) -----------
+    if not args.no_cpu and rank == 0 and world == 1:
         from oracle import qmc_oracle as orc
         m = orc.model_from_cfc(cfc)
         # the one-GPU box shares its host: use its CPU allotment, not every
