@@ -649,78 +649,180 @@ struct EstArgs {
                               // density: bin size L / num_bins
 };
 
-static constexpr int EST_BLOCKS = 512;
+static constexpr int EST_BLOCKS = 1024;
 static constexpr int EST_MAXK = 256;        // modes / bins supported per call
 static constexpr int EST_CH = EST_MAXK / 64;
 
-// Static structure factor parts of every yielded walker, lane = mode:
-// rho_k = sum_i exp(i k z_i), parts (|rho_k|^2, Re, Im); mixed estimator or
-// forward-walking transport through the cloning table
+// Static structure factor parts of every yielded walker:
+// rho_m = sum_i exp(i k_m z_i), k_m = 2 pi m / L, parts (|rho_m|^2, Re, Im);
+// mixed estimator or forward-walking transport through the cloning table
 // (qmc_base/jastrow/dmc.py:363-461, 483-566).
-__global__ void __launch_bounds__(BLOCK) dmc_ssf_kernel(EstArgs a)
+//
+// The sum over particles IS a contraction, so it runs on the matrix cores:
+// with m = KD a + b,  exp(i m t_i) = F_a(i) E_b(i),  F_a = exp(i KD a t_i),
+// E_b = exp(i b t_i), and  rho[a][b] = sum_i F_a(i) E_b(i)  is a
+// (2 KD x N) x (N x 2 KD) real product over the particle index, accumulated
+// with v_mfma_f64_16x16x4_f64 (K = 4 particles per instruction).  The two
+// factor tables cost one sincos and KD - 1 complex rotations per particle
+// instead of one sincos per (mode, particle): 2560 -> ~200 VALU instructions
+// per walker at N = 64, 64 modes, plus 16 MFMAs on the otherwise idle matrix
+// pipe.  KD = 8 packs Re/Im of both factors into one 16x16 tile (<= 64
+// modes); KD = 16 uses four tiles (<= 256 modes).
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int KD>
+struct SsfShape {
+    static constexpr int CH = 32;                    // particles per chunk
+    static constexpr int ROWS = 2 * KD;              // Re and Im rows
+    static constexpr int RS = CH + 4;                // padded row stride
+    static constexpr int WAVE_DOUBLES = 2 * ROWS * RS;
+    static constexpr int NM = (KD == 8) ? 1 : 4;     // modes per lane
+};
+
+// Table of exp(i b t), b = 0..KD-1, of one particle: rows [0,KD) real parts,
+// rows [KD,2KD) imaginary parts, column = particle slot.
+template <int KD>
+__device__ __forceinline__ void ssf_fill_table(double *T, int col, double u,
+                                               bool valid)
 {
+    constexpr int RS = SsfShape<KD>::RS;
+    double s1, c1;
+    sincos_halfpi(u, s1, c1);
+    double er = valid ? 1.0 : 0.0, ei = 0.0;
+    T[col] = er;
+    T[KD * RS + col] = 0.0;
+#pragma unroll
+    for (int b = 1; b < KD; ++b) {
+        double nr = er * c1 - ei * s1;
+        double ni = er * s1 + ei * c1;
+        er = nr; ei = ni;
+        T[b * RS + col] = er;
+        T[(KD + b) * RS + col] = ei;
+    }
+}
+
+template <int KD>
+__global__ void __launch_bounds__(BLOCK) dmc_ssf_mfma_kernel(EstArgs a)
+{
+    using S = SsfShape<KD>;
+    constexpr int CH = S::CH, RS = S::RS, NM = S::NM;
     extern __shared__ double smem[];
-    __shared__ double red[BLOCK / 64][EST_MAXK][3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *zs = smem + (size_t)wave * a.n;
+    double *X = smem + (size_t)wave * S::WAVE_DOUBLES;   // F_a (rows of D)
+    double *Y = X + S::ROWS * RS;                        // E_b (columns of D)
     const long long nw = a.ctl->nw;
     const long long wstride = (long long)gridDim.x * (BLOCK / 64);
-    double acc[EST_CH][3];
+    const int quad = lane >> 4, idx = lane & 15;
+    // modes owned by this lane when the results are handed out
+    int mo[NM];
 #pragma unroll
-    for (int c = 0; c < EST_CH; ++c) acc[c][0] = acc[c][1] = acc[c][2] = 0.0;
+    for (int r = 0; r < NM; ++r)
+        mo[r] = (KD == 8) ? lane : 16 * (quad + 4 * r) + idx;
+    double acc[NM][3];
+#pragma unroll
+    for (int r = 0; r < NM; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
     const bool accumulate = !a.pure || a.step_idx < a.pfw;
     for (long long s = (long long)blockIdx.x * (BLOCK / 64) + wave; s < nw;
          s += wstride) {
         const long long par = a.ref[s];
+        double re[NM], im[NM];
+#pragma unroll
+        for (int r = 0; r < NM; ++r) re[r] = im[r] = 0.0;
         if (accumulate) {
-            for (int i = lane; i < a.n; i += 64) zs[i] = a.ppos[par * a.n + i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v4d Drr = {0, 0, 0, 0}, Dri = {0, 0, 0, 0}, Dir = {0, 0, 0, 0},
+                Dii = {0, 0, 0, 0};
+            for (int c0 = 0; c0 < a.n; c0 += CH) {
+                {
+                    // lanes 0..31 build E of particle `lane`, lanes 32..63
+                    // build F of particle `lane - 32`
+                    const int pl = lane & 31;
+                    const int i = c0 + pl;
+                    const bool valid = i < a.n;
+                    const double u = a.scale * (valid ? a.ppos[par * a.n + i] : 0.0);
+                    ssf_fill_table<KD>(lane < 32 ? Y : X, pl,
+                                       lane < 32 ? u : (double)KD * u, valid);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int left = a.n - c0;
+                const int ngroups = (left >= CH ? CH : left + 3) / 4;
+                for (int g = 0; g < ngroups; ++g) {
+                    const int col = 4 * g + quad;       // particle of this k
+                    if (KD == 8) {
+                        const double xa = X[idx * RS + col];
+                        const double yb = Y[idx * RS + col];
+                        Drr = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, Drr,
+                                                                   0, 0, 0);
+                    } else {
+                        const double xr = X[idx * RS + col];
+                        const double xi = X[(KD + idx) * RS + col];
+                        const double yr = Y[idx * RS + col];
+                        const double yi = Y[(KD + idx) * RS + col];
+                        Drr = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, yr, Drr, 0, 0, 0);
+                        Dri = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, yi, Dri, 0, 0, 0);
+                        Dir = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, yr, Dir, 0, 0, 0);
+                        Dii = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, yi, Dii, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();    // tables are rewritten next
+            }
+            if (KD == 8) {
+                // one tile holds the four quadrants RR | RI / IR | II; element
+                // (row, col) sits in lane (col, row & 3), register row >> 2
+                // (f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 reg)
+                double *Dl = X;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Dl[(quad + 4 * r) * 16 + idx] = Drr[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int fa = lane >> 3, eb = lane & 7;
+                re[0] = Dl[fa * 16 + eb] - Dl[(8 + fa) * 16 + 8 + eb];
+                im[0] = Dl[fa * 16 + 8 + eb] + Dl[(8 + fa) * 16 + eb];
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    re[r] = Drr[r] - Dii[r];
+                    im[r] = Dri[r] + Dir[r];
+                }
+            }
         }
 #pragma unroll
-        for (int c = 0; c < EST_CH; ++c) {
-            const int mo = c * 64 + lane;
-            if (c * 64 >= a.K) break;
+        for (int r = 0; r < NM; ++r) {
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-            if (mo < a.K) {
+            if (mo[r] < a.K) {
                 if (accumulate) {
-                    double re = 0.0, im = 0.0;
-                    const double f = (double)mo * a.scale;
-                    for (int i = 0; i < a.n; ++i) {
-                        double sn, cs;
-                        sincos_halfpi(f * zs[i], sn, cs);
-                        re += cs;
-                        im += sn;
-                    }
-                    v0 = fma(re, re, im * im); v1 = re; v2 = im;
+                    v0 = fma(re[r], re[r], im[r] * im[r]);
+                    v1 = re[r]; v2 = im[r];
                 }
                 if (a.pure) {
-                    const double *pp = a.aux_prev + ((size_t)par * a.K + mo) * 3;
+                    const double *pp = a.aux_prev + ((size_t)par * a.K + mo[r]) * 3;
                     v0 += pp[0]; v1 += pp[1]; v2 += pp[2];
-                    double *ap = a.aux_act + ((size_t)s * a.K + mo) * 3;
+                    double *ap = a.aux_act + ((size_t)s * a.K + mo[r]) * 3;
                     ap[0] = v0; ap[1] = v1; ap[2] = v2;
                 }
             }
-            acc[c][0] += v0; acc[c][1] += v1; acc[c][2] += v2;
+            acc[r][0] += v0; acc[r][1] += v1; acc[r][2] += v2;
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    // fixed-order block reduction: waves 0..3, then the reduce kernel sums the
-    // blocks in index order
-#pragma unroll
-    for (int c = 0; c < EST_CH; ++c) {
-        const int mo = c * 64 + lane;
-        red[wave][mo][0] = acc[c][0];
-        red[wave][mo][1] = acc[c][1];
-        red[wave][mo][2] = acc[c][2];
-    }
+    // fixed-order block reduction: waves 0..3 (the tables' LDS is reused),
+    // then the reduce kernel sums the blocks in index order
     __syncthreads();
-    for (int idx = threadIdx.x; idx < a.K * 3; idx += BLOCK) {
-        const int mo = idx / 3, cpt = idx % 3;
+    double *red = smem;                    // [BLOCK/64][K][3]
+#pragma unroll
+    for (int r = 0; r < NM; ++r)
+        if (mo[r] < a.K) {
+            double *q = red + ((size_t)wave * a.K + mo[r]) * 3;
+            q[0] = acc[r][0]; q[1] = acc[r][1]; q[2] = acc[r][2];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.K * 3; i += BLOCK) {
         double t = 0.0;
-        for (int w = 0; w < BLOCK / 64; ++w) t += red[w][mo][cpt];
-        a.partial[((size_t)blockIdx.x * a.K + mo) * 3 + cpt] = t;
+        for (int w = 0; w < BLOCK / 64; ++w) t += red[(size_t)w * a.K * 3 + i];
+        a.partial[(size_t)blockIdx.x * a.K * 3 + i] = t;
     }
 }
 
@@ -781,15 +883,38 @@ __global__ void __launch_bounds__(BLOCK) dmc_density_kernel(EstArgs a)
     }
 }
 
-// iter[step][k][c] = (sum over blocks, in order) / divisor
-__global__ void est_reduce_kernel(const double *partial, int nblocks, int KC,
-                                  double divisor, double *out)
+// iter[step][k][c] = (sum over blocks) / divisor.  Fixed summation order:
+// eight contiguous segments of blocks summed in index order by eight threads
+// (independent loads in flight), the segment sums then added in order.
+__global__ void __launch_bounds__(256)
+est_reduce_kernel(const double *__restrict__ partial, int nblocks, int KC,
+                  double divisor, double *__restrict__ out)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= KC) return;
+    __shared__ double seg_sum[8][32];
+    const int j = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + j;
+    const int per = (nblocks + 7) / 8;
+    const int b0 = seg * per, b1 = min(nblocks, b0 + per);
     double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += partial[(size_t)b * KC + idx];
-    out[idx] = t / divisor;
+    if (idx < KC) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            double v0 = partial[(size_t)b * KC + idx];
+            double v1 = partial[(size_t)(b + 1) * KC + idx];
+            double v2 = partial[(size_t)(b + 2) * KC + idx];
+            double v3 = partial[(size_t)(b + 3) * KC + idx];
+            t += v0; t += v1; t += v2; t += v3;
+        }
+        for (; b < b1; ++b) t += partial[(size_t)b * KC + idx];
+    }
+    seg_sum[seg][j] = t;
+    __syncthreads();
+    if (seg == 0 && idx < KC) {
+        double r = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r += seg_sum[q][j];
+        out[idx] = r / divisor;
+    }
 }
 
 
@@ -1861,13 +1986,23 @@ static int dmc_enqueue_estimators(qmc_dmc *d, long long step_idx)
         a.aux_prev = d->ssf_aux[prev]; a.aux_act = d->ssf_aux[act];
         a.K = M; a.pure = d->est.ssf_pure; a.pfw = d->est.ssf_pfw;
         a.scale = 4.0 / e->dm.L;
-        const size_t lds = (size_t)(BLOCK / 64) * a.n * sizeof(double);
-        hipLaunchKernelGGL(dmc_ssf_kernel, dim3(EST_BLOCKS), dim3(BLOCK), lds,
-                           e->stream, a);
+        if (M <= 64) {
+            const size_t lds = (size_t)(BLOCK / 64) *
+                               SsfShape<8>::WAVE_DOUBLES * sizeof(double);
+            allow_lds(dmc_ssf_mfma_kernel<8>, lds);
+            hipLaunchKernelGGL(dmc_ssf_mfma_kernel<8>, dim3(EST_BLOCKS),
+                               dim3(BLOCK), lds, e->stream, a);
+        } else {
+            const size_t lds = (size_t)(BLOCK / 64) *
+                               SsfShape<16>::WAVE_DOUBLES * sizeof(double);
+            allow_lds(dmc_ssf_mfma_kernel<16>, lds);
+            hipLaunchKernelGGL(dmc_ssf_mfma_kernel<16>, dim3(EST_BLOCKS),
+                               dim3(BLOCK), lds, e->stream, a);
+        }
         double div = 1.0;
         if (a.pure) div = step_idx < a.pfw ? (double)(step_idx + 1)
                                            : (double)a.pfw;
-        hipLaunchKernelGGL(est_reduce_kernel, dim3((M * 3 + 255) / 256),
+        hipLaunchKernelGGL(est_reduce_kernel, dim3((M * 3 + 31) / 32),
                            dim3(256), 0, e->stream, d->est_partial, EST_BLOCKS,
                            M * 3, div, d->iter_ssf + (size_t)step_idx * M * 3);
     }
@@ -1881,7 +2016,7 @@ static int dmc_enqueue_estimators(qmc_dmc *d, long long step_idx)
         double div = 1.0;
         if (a.pure) div = step_idx < a.pfw ? (double)(step_idx + 1)
                                            : (double)a.pfw;
-        hipLaunchKernelGGL(est_reduce_kernel, dim3((B + 255) / 256), dim3(256),
+        hipLaunchKernelGGL(est_reduce_kernel, dim3((B + 31) / 32), dim3(256),
                            0, e->stream, d->est_partial, EST_BLOCKS, B, div,
                            d->iter_dens + (size_t)step_idx * B);
     }

@@ -358,3 +358,38 @@ def test_trajectories_at_other_cutoffs(oracle, cutoff):
         assert close(ser.energy[t], o.energy, 1e-9), t
     d.close()
     eng.close()
+
+
+@pytest.mark.parametrize('n,modes', [(16, 100), (16, 256), (37, 64), (70, 64),
+                                     (70, 130), (9, 3)])
+def test_ssf_matrix_core_kernel_vs_numpy(n, modes):
+    """S(k) parts of one time step against a direct numpy evaluation on the
+    yielded walkers: both tilings of the MFMA kernel (<= 64 modes: one packed
+    tile; <= 256: four tiles), particle counts that are not multiples of the
+    MFMA K = 4 nor of the 64-particle chunk."""
+    from math import pi
+    from phd_qmclib_amd import mrbp_qmc
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    spec = mrbp_qmc.Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                         interaction_strength=2, boson_number=n,
+                         supercell_size=n, tbf_contact_cutoff=0.25 * n)
+    eng = ModelEngine(spec.cfc_spec)
+    rng = np.random.RandomState(n + modes)
+    W = 300
+    ens = DmcEnsemble(eng, 1e-3, 384, W, 0.5, rng_seed=5)
+    ens.set_state(n * rng.random_sample((W, n)))
+    ens.set_estimators(num_modes=modes)
+    ser, ssf, _ = ens.run_block_est(2, True)
+    st = ens.get_state()
+    nw = st.num_walkers
+    assert nw == int(ser.num_walkers[-1])
+    z = st.confs[:nw, 0, :]
+    k = 2 * pi * np.arange(modes) / n
+    ph = np.exp(1j * k[None, :, None] * z[:, None, :]).sum(axis=2)   # [w, m]
+    ref = np.stack([(np.abs(ph) ** 2).sum(0), ph.real.sum(0), ph.imag.sum(0)],
+                   axis=1)
+    scale = np.abs(ref).max()
+    assert np.abs(ssf[-1] - ref).max() <= 1e-11 * scale, \
+        np.abs(ssf[-1] - ref).max() / scale
+    ens.close()
+    eng.close()
