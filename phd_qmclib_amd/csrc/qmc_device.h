@@ -301,12 +301,16 @@ __device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
     Yout = Y;
 }
 
-// LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of 2*G*P
-// doubles; the entry of particle (lane g, register b) is stored at b*2G + g
-// and b*2G + G + g so a rotated read (g - k) never needs a modulo.
+// LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of
+// DUP*G*P doubles.  For P <= 2 every entry is stored twice (particle (lane g,
+// register b) at b*2G + g and b*2G + G + g) so a rotated read (g - k) never
+// needs a modulo; for P >= 4 the copy would cap the occupancy through LDS
+// (P = 8: 128 KB per block), so the table is stored once and the rotated
+// index is masked (one v_and per partner table, i.e. per 4-8 pairs).
 template <int G, int P, bool ZCLASS>
 struct GroupLds {
-    static constexpr int ROW = 2 * G * P;
+    static constexpr int DUP = (P >= 4) ? 1 : 2;
+    static constexpr int ROW = DUP * G * P;
     static constexpr int DOUBLES = (ZCLASS ? 5 : 4) * ROW;
 };
 
@@ -323,14 +327,21 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                                             double (&eith)[P], double &E,
                                             double &logwf)
 {
-    constexpr int ROW = 2 * G * P;
+    constexpr int DUP = GroupLds<G, P, ZCLASS>::DUP;
+    constexpr int ROW = GroupLds<G, P, ZCLASS>::ROW;
+    // Own particles are processed PA at a time: with P = 8 the tables of all
+    // eight (96 VGPRs) would leave one wave per SIMD, so the rotation runs in
+    // two passes of four own particles (tables re-read from LDS).
+    constexpr int PA = (P > 4) ? 4 : P;
+    constexpr int NPASS = P / PA;
     double *lS = lds, *lC = lds + ROW, *lSU = lds + 2 * ROW,
            *lCU = lds + 3 * ROW, *lZ = lds + 4 * ROW;
     const int n = m.n;
-    PTab t[P];
-    double aks[P], akc[P];   // a_long * (sin, cos)(pi z / L)
+    PTab t[PA];
+    double aks[PA], akc[PA];   // a_long * (sin, cos)(pi z / L)
     bool ok[P];
-    double kin1[P];          // one-body kinetic + potential
+    double kin1[P];          // one-body kinetic + potential (ITH)
+    double kin1_sum = 0.0;   // their sum over the own particles (!ITH)
     double prodS = 1.0, prodL = 1.0;   // running products of pair factors (WF)
     double prod1 = 1.0;      // product of the one-body factors (WF)
     int expS = 0, expL = 0;  // binary exponents split off the products
@@ -346,26 +357,34 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         ok[a] = !PAD || (gl + G * a) < n;
-        F[a] = 0.0; kin1[a] = 0.0; T[a] = 0.0; Kown[a] = 0.0; KT[a] = 0.0;
-        aks[a] = 0.0; akc[a] = 0.0;
+        F[a] = 0.0; T[a] = 0.0; Kown[a] = 0.0; KT[a] = 0.0;
+        if (ITH) kin1[a] = 0.0;
         if (!m.is_ideal) {
-            sincos_halfpi(z[a] * m.two_over_L, t[a].s, t[a].c);
-            sincos_halfpi(z[a] * m.k2_2pi, t[a].su, t[a].cu);
-            aks[a] = m.a_long * t[a].s;
-            akc[a] = m.a_long * t[a].c;
-            int i0 = a * 2 * G + gl;
-            lS[i0] = t[a].s;   lS[i0 + G] = t[a].s;
-            lC[i0] = t[a].c;   lC[i0 + G] = t[a].c;
-            lSU[i0] = t[a].su; lSU[i0 + G] = t[a].su;
-            lCU[i0] = t[a].cu; lCU[i0 + G] = t[a].cu;
-            if (ZCLASS) { lZ[i0] = z[a]; lZ[i0 + G] = z[a]; }
+            PTab ta;
+            sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
+            sincos_halfpi(z[a] * m.k2_2pi, ta.su, ta.cu);
+            if (NPASS == 1) {
+                t[a % PA] = ta;
+                aks[a % PA] = m.a_long * ta.s;
+                akc[a % PA] = m.a_long * ta.c;
+            }
+            int i0 = a * DUP * G + gl;
+            lS[i0] = ta.s; lC[i0] = ta.c; lSU[i0] = ta.su; lCU[i0] = ta.cu;
+            if (ZCLASS) lZ[i0] = z[a];
+            if (DUP == 2) {
+                lS[i0 + G] = ta.s; lC[i0 + G] = ta.c;
+                lSU[i0 + G] = ta.su; lCU[i0 + G] = ta.cu;
+                if (ZCLASS) lZ[i0 + G] = z[a];
+            }
+        } else if (NPASS == 1) {
+            aks[a % PA] = 0.0; akc[a % PA] = 0.0;
         }
         if (!m.is_free) {
             double ldz, kp, f1;
             one_body(m, z[a], ldz, kp, f1);
             if (ok[a]) {
                 F[a] = ldz;
-                kin1[a] = kp;
+                if (ITH) kin1[a] = kp; else kin1_sum += kp;
                 if (WF) prod1 *= f1;
             }
         }
@@ -377,6 +396,13 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     do {                                                                      \
         e += __builtin_amdgcn_frexp_exp(p);                                   \
         p = __builtin_amdgcn_frexp_mant(p);                                   \
+    } while (0)
+    // own table of particle (lane gl, register a) back from LDS
+#define QMC_LOAD_OWN(dst, a)                                                  \
+    do {                                                                      \
+        const int i0_ = (a) * DUP * G + gl;                                   \
+        (dst).s = lS[i0_]; (dst).c = lC[i0_];                                 \
+        (dst).su = lSU[i0_]; (dst).cu = lCU[i0_];                             \
     } while (0)
 
     if (!m.is_ideal) {
@@ -408,10 +434,20 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // ---- k = 0: pairs inside the lane ----
 #pragma unroll
         for (int a = 0; a < P; ++a) {
+            PTab ta; double aksa, akca;
+            if (NPASS == 1) {
+                ta = t[a % PA]; aksa = aks[a % PA]; akca = akc[a % PA];
+            } else if (a + 1 < P) {
+                QMC_LOAD_OWN(ta, a);
+                aksa = m.a_long * ta.s; akca = m.a_long * ta.c;
+            }
 #pragma unroll
             for (int b = a + 1; b < P; ++b) {
+                PTab tb;
+                if (NPASS == 1) tb = t[b % PA];
+                else QMC_LOAD_OWN(tb, b);
                 double q, Y; bool sh; unsigned long long shm;
-                pair_core<ZCLASS>(pc, t[a], aks[a], akc[a], z[a], t[b], z[b], q,
+                pair_core<ZCLASS>(pc, ta, aksa, akca, z[a], tb, z[b], q,
                                   Y, sh, shm);
                 if (WAVE_COUNT)
                     ns_wave += __popcll(shm);
@@ -424,48 +460,55 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                     }
                 }
             }
+            if (WF && P > 4) { QMC_FOLD(prodS, expS); QMC_FOLD(prodL, expL); }
         }
 
         // ---- k = 1 .. G/2: rotate over partner lanes ----
         const int lane = threadIdx.x & 63;
         const int src = lane - gl + ((gl + G - 1) & (G - 1));
-        // One rotation step; LAST is a compile-time flag: the final half step
-        // (k = G/2) visits every pair from both sides, so each side only
-        // updates its own particle and the lower half of the lanes tallies.
-#define QMC_KSTEP(k, LAST)                                                    \
+        // One rotation step of pass H (own particles H*PA .. H*PA+PA-1);
+        // LAST is a compile-time flag: the final half step (k = G/2) visits
+        // every pair from both sides, so each side only updates its own
+        // particle and the lower half of the lanes tallies.
+#define QMC_KSTEP(H, k, LAST)                                                 \
         {                                                                     \
             const bool count_pair = !(LAST) || gl < G / 2;                    \
-            /* partner-major order: one partner table live at a time, so the  \
-               P = 4, 8 shapes do not hold P tables in registers */           \
+            /* partner-major order: one partner table live at a time */       \
             _Pragma("unroll")                                                 \
             for (int b = 0; b < P; ++b) {                                     \
                 PTab pb;                                                      \
-                const int idx = b * 2 * G + gl + G - (k);                     \
+                const int idx = (DUP == 2) ? b * 2 * G + gl + G - (k)         \
+                                           : b * G + ((gl - (k)) & (G - 1));  \
                 pb.s = lS[idx]; pb.c = lC[idx];                               \
                 pb.su = lSU[idx]; pb.cu = lCU[idx];                           \
                 const double pz = ZCLASS ? lZ[idx] : 0.0;                     \
                 int pl = gl - (k); if (pl < 0) pl += G;                       \
                 const bool pok = !PAD || (pl + G * b) < n;                    \
                 _Pragma("unroll")                                             \
-                for (int a = 0; a < P; ++a) {                                 \
+                for (int a = 0; a < PA; ++a) {                                \
+                    constexpr int ao_base = (H) * PA;                         \
                     double q, Y; bool sh; unsigned long long shm;            \
-                    pair_core<ZCLASS>(pc, t[a], aks[a], akc[a], z[a], pb,     \
-                                      pz, q, Y, sh, shm);                     \
+                    pair_core<ZCLASS>(pc, t[a], aks[a], akc[a],               \
+                                      z[ao_base + a], pb, pz, q, Y, sh, shm); \
                     /* G = 64: the lower half of the lanes is bits 0..31 */   \
                     if (WAVE_COUNT)                                           \
                         ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \
                                                    : shm);                    \
-                    if (!PAD || (ok[a] && pok)) {                             \
-                        F[a] += q;                                            \
+                    if (!PAD || (ok[ao_base + a] && pok)) {                   \
+                        F[ao_base + a] += q;                                  \
                         if (!(LAST)) T[b] -= q;                               \
                         if (!(LAST) || count_pair) { QMC_TALLY(q, Y, sh); }   \
                         if (ITH) {                                            \
                             double kk = QMC_PAIR_KIN(q, sh);                  \
-                            Kown[a] += kk;                                    \
+                            Kown[ao_base + a] += kk;                          \
                             if (!(LAST)) KT[b] += kk;                         \
                         }                                                     \
                     }                                                         \
                 }                                                             \
+                /* large P: keep the scheduler from interleaving the pairs   \
+                   of different partners (it trades the occupancy away       \
+                   for it: 282 registers instead of ~180 at P = 8) */        \
+                if (P >= 4) __builtin_amdgcn_sched_barrier(0);                \
             }                                                                 \
             if (!(LAST)) {                                                    \
                 _Pragma("unroll")                                             \
@@ -479,18 +522,37 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 QMC_FOLD(prodL, expL);                                        \
             }                                                                 \
         }
-        // (kept rolled: unrolled, the scheduler hoists the LDS reads of every
-        // copy and the kernel loses half its occupancy -- measured -8 %)
-        for (int k = 1; k < G / 2; ++k)
-            QMC_KSTEP(k, false)
-        QMC_KSTEP(G / 2, true)
-#undef QMC_KSTEP
-        // deliver the travelling sums to their owners (lane gl ^ G/2 holds them)
-#pragma unroll
-        for (int b = 0; b < P; ++b) {
-            F[b] += __shfl_xor(T[b], G / 2, 64);
-            if (ITH) Kown[b] += __shfl_xor(KT[b], G / 2, 64);
+#define QMC_PASS(H)                                                           \
+        if ((H) < NPASS) {                                                    \
+            if (NPASS > 1) {                                                  \
+                _Pragma("unroll")                                             \
+                for (int a = 0; a < PA; ++a) {                                \
+                    QMC_LOAD_OWN(t[a], (H) * PA + a);                         \
+                    aks[a] = m.a_long * t[a].s;                               \
+                    akc[a] = m.a_long * t[a].c;                               \
+                }                                                             \
+            }                                                                 \
+            /* (kept rolled: unrolled, the scheduler hoists the LDS reads of \
+               every copy and the kernel loses half its occupancy: -8 %) */  \
+            for (int k = 1; k < G / 2; ++k)                                   \
+                QMC_KSTEP(H, k, false)                                        \
+            QMC_KSTEP(H, G / 2, true)                                         \
+            /* deliver the travelling sums to their owners (lane gl ^ G/2    \
+               holds them) and start the next pass from zero */              \
+            _Pragma("unroll")                                                 \
+            for (int b = 0; b < P; ++b) {                                     \
+                F[b] += __shfl_xor(T[b], G / 2, 64);                          \
+                T[b] = 0.0;                                                   \
+                if (ITH) {                                                    \
+                    Kown[b] += __shfl_xor(KT[b], G / 2, 64);                  \
+                    KT[b] = 0.0;                                              \
+                }                                                             \
+            }                                                                 \
         }
+        QMC_PASS(0)
+        QMC_PASS(1)
+#undef QMC_PASS
+#undef QMC_KSTEP
     }
 
     // ---- local energy ----
@@ -510,9 +572,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         if (!WAVE_COUNT)
             pk += m.k2sq * (double)nshort + m.b_long * (double)nlong;
         e_lane = 2.0 * pk;
+        e_lane += kin1_sum;
 #pragma unroll
         for (int a = 0; a < P; ++a)
-            if (ok[a]) e_lane += kin1[a] - F[a] * F[a];
+            if (ok[a]) e_lane -= F[a] * F[a];
     }
     E = group_sum<G>(e_lane);
     if (WAVE_COUNT && !ITH && !m.is_ideal) {
@@ -531,6 +594,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         if (WAVE_COUNT) logwf += (double)ns_wave * m.log_am;
     }
 #undef QMC_FOLD
+#undef QMC_LOAD_OWN
 #undef QMC_TALLY
 #undef QMC_PAIR_KIN
 }

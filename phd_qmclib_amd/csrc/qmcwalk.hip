@@ -203,18 +203,16 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
     const bool forced = a.forced != 0;
 
-    double z[P], zn[P];
-    int lab[P], labn[P];      // original particle index held by each lane
+    double zn[P];
+    int labn[P];              // original particle index held by each lane
     double ua = 1.0;          // accept uniform (particle 0's spare double)
-    double uas[P];
+    double mine = -1.0;       // >= 0 only in the lane that holds particle 0
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = gl + G * p;
-        uas[p] = -1.0;
-        z[p] = (i < n) ? a.pos[wr * n + i] : 0.0;
-        lab[p] = (i < n) ? (int)a.label[wr * n + i] : i;
-        labn[p] = lab[p];
-        const unsigned li = (unsigned)lab[p];
+        const double zp = (i < n) ? a.pos[wr * n + i] : 0.0;
+        labn[p] = (i < n) ? (int)a.label[wr * n + i] : i;
+        const unsigned li = (unsigned)labn[p];
         double d = 0.0;
         if (!forced && i < n) {
             if (!LEAN && a.tape) {
@@ -232,11 +230,11 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
                                 u1);
                 d = (u0 - 0.5) * a.move_spread;
                 // the accept draw is the spare double of particle 0
-                uas[p] = (li == 0u) ? u1 : -1.0;
+                mine = (li == 0u) ? u1 : mine;
             }
         }
         // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
-        zn[p] = forced ? z[p] : wrap_box(z[p] + d, m.L);
+        zn[p] = forced ? zp : wrap_box(zp + d, m.L);
     }
     if (!forced) resort_step<G, P>(zn, labn, gl, a.step, n, m.L, m.half_L);
     double F[P], ei[P], e_new, wf_new;
@@ -252,9 +250,6 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
         } else {
             // exactly one lane of the group holds particle 0 (ua >= 0 there):
             // find it with a ballot and read its value
-            double mine = uas[0];
-#pragma unroll
-            for (int p = 1; p < P; ++p) mine = (uas[p] >= 0.0) ? uas[p] : mine;
             const unsigned long long bal = __ballot(mine >= 0.0);
             if (G == 64) {
                 const int src = __builtin_amdgcn_readfirstlane(
@@ -296,10 +291,13 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = gl + G * p;
-            // series in the original particle order
-            if (i < n)
-                a.ser_pos[(a.y * a.W + w) * n + (acc ? labn[p] : lab[p])] =
-                    acc ? zn[p] : z[p];
+            // series in the original particle order (a rejected move leaves
+            // pos / label as they were: read them back)
+            if (i < n) {
+                const int lb = acc ? labn[p] : (int)a.label[w * n + i];
+                a.ser_pos[(a.y * a.W + w) * n + lb] =
+                    acc ? zn[p] : a.pos[w * n + i];
+            }
         }
     }
     if (gl == 0) {
@@ -568,17 +566,22 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         z[p] = zz;
     }
     resort_step<G, P>(z, lab, gl, step, n, m.L, m.half_L);
+    // positions and labels leave now: not live across the pair sum
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (active && i < n) {
+            a.cpos[s * n + i] = z[p];
+            a.clabel[s * n + i] = (unsigned short)lab[p];
+        }
+    }
     double F[P], ei[P], e_next, wf;
     eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, e_next, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = gl + G * p;
-        if (i < n) {
-            a.cpos[s * n + i] = z[p];
-            a.cdrift[s * n + i] = F[p];
-            a.clabel[s * n + i] = (unsigned short)lab[p];
-        }
+        if (i < n) a.cdrift[s * n + i] = F[p];
     }
     if (gl == 0) {
         double e_par = a.penergy[par];
@@ -983,9 +986,14 @@ template <template <int, int, bool, bool> class L, typename... A>
 static int dispatch_shape(const qmc_engine *e, A &&...args)
 {
     const bool zc = e->dm.zclass != 0;
+    // The masked variant is also the leaner one in registers (its per-pair
+    // guards stop the compiler from keeping several pairs in flight: 110-160
+    // VGPRs against 134-282 at P = 4, 8), and occupancy is what the large
+    // shapes lack; each kernel family says from which P it wants it.
+    const bool masked = e->pad || L<16, 1, false, false>::want_mask(e->P);
 #define QMC_CASE(g, p)                                                        \
     if (e->G == g && e->P == p) {                                             \
-        if (e->pad) {                                                         \
+        if (masked) {                                                         \
             if (zc) return L<g, p, true, true>::run(e, args...);              \
             return L<g, p, true, false>::run(e, args...);                     \
         }                                                                     \
@@ -1023,6 +1031,7 @@ static unsigned grid_for(long long nwalkers)
 
 template <int G, int P, bool PAD, bool ZC>
 struct LaunchEval {
+    static bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const EvalArgs &a)
     {
         if (a.nconf <= 0) return 0;
@@ -1038,6 +1047,7 @@ struct LaunchEval {
 
 template <int G, int P, bool PAD, bool ZC>
 struct LaunchPrep {
+    static bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const PrepArgs &a)
     {
         if (a.nconf <= 0) return 0;
@@ -1053,6 +1063,7 @@ struct LaunchPrep {
 
 template <int G, int P, bool PAD, bool ZC>
 struct LaunchVmc {
+    static bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const VmcArgs &a)
     {
         const size_t lds = lds_bytes<G, P, ZC>();
@@ -1076,6 +1087,9 @@ struct LaunchVmc {
 
 template <int G, int P, bool PAD, bool ZC>
 struct LaunchEvolve {
+    // P = 8 is capped at two waves per SIMD by LDS either way: unmasked
+    // (186 VGPRs) it saves the guards
+    static bool want_mask(int np) { return np == 4; }
     static int run(const qmc_engine *e, const EvolveArgs &a)
     {
         const size_t lds = lds_bytes<G, P, ZC>();
