@@ -302,14 +302,14 @@ __device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
 }
 
 // LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of
-// DUP*G*P doubles.  For P <= 2 every entry is stored twice (particle (lane g,
-// register b) at b*2G + g and b*2G + G + g) so a rotated read (g - k) never
-// needs a modulo; for P >= 4 the copy would cap the occupancy through LDS
-// (P = 8: 128 KB per block), so the table is stored once and the rotated
-// index is masked (one v_and per partner table, i.e. per 4-8 pairs).
+// DUP*G*P doubles.  For P = 1 every entry is stored twice (lane g at g and
+// G + g) so a rotated read (g - k) never needs a modulo; for P >= 2 the copy
+// costs occupancy through LDS (P = 8: 128 KB per block, one wave per SIMD), so
+// the table is stored once and the rotated index is masked (one v_and per
+// partner table, i.e. per 2-8 pairs).
 template <int G, int P, bool ZCLASS>
 struct GroupLds {
-    static constexpr int DUP = (P >= 4) ? 1 : 2;
+    static constexpr int DUP = (P >= 2) ? 1 : 2;
     static constexpr int ROW = DUP * G * P;
     static constexpr int DOUBLES = (ZCLASS ? 5 : 4) * ROW;
 };
