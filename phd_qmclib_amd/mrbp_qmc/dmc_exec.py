@@ -147,3 +147,72 @@ class Proc:
 
     def exec(self, proc_input: ProcInput):
         return proc_base.exec_dmc(self, proc_input)
+
+
+# ---- result files + command-line application --------------------------
+from ..qmc_exec import cli_app as _qcli, config as _qcfg, io as _qio  # noqa: E402
+from ..qmc_exec.data import dmc as _dmc_data  # noqa: E402
+from .vmc_exec import MODEL_SYS_CONF_TYPE  # noqa: E402
+
+#: on-disk record of the cloning table (qmc_base/dmc.py:381-384)
+branching_spec_dtype = np.dtype([('CLONING_FACTOR', np.int32),
+                                 ('CLONING_REF', np.int32)])
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class HDF5FileHandler(_qio.HDF5FileHandler):
+    """Structured HDF5 files with DMC procedure results
+    (mrbp_qmc/dmc_exec/io.py, qmc_exec/dmc/io.py:11-98)."""
+    sampling_type: t.ClassVar[str] = 'dmc'
+
+    def save_state(self, state, group):
+        maxw = int(state.max_num_walkers)
+        rec = np.zeros(maxw, dtype=branching_spec_dtype)
+        bs = state.branching_spec
+        if bs is not None:
+            if bs.cloning_factor is not None:
+                rec['CLONING_FACTOR'] = np.asarray(bs.cloning_factor)[:maxw]
+            rec['CLONING_REF'] = np.asarray(bs.cloning_ref)[:maxw]
+        group.create_dataset('branching_spec', data=rec)
+        group.create_dataset('confs', data=state.confs)
+        props_group = group.require_group('props')
+        props_group.create_dataset('energy', data=state.props.energy)
+        props_group.create_dataset('weight', data=state.props.weight)
+        props_group.create_dataset('mask',
+                                   data=np.asarray(state.props.mask, bool))
+        group.attrs.update({
+            'energy': float(state.energy), 'weight': float(state.weight),
+            'num_walkers': int(state.num_walkers),
+            'ref_energy': float(state.ref_energy),
+            'accum_energy': float(state.accum_energy),
+            'max_num_walkers': maxw})
+
+    def load_state(self, group):
+        rec = group.get('branching_spec')[()]
+        props = group.get('props')
+        state_props = dmc_base.StateProps(props.get('energy')[()],
+                                          props.get('weight')[()],
+                                          props.get('mask')[()])
+        bs = dmc_base.BranchingSpec(
+            np.asarray(rec['CLONING_FACTOR'], dtype=np.int64),
+            np.asarray(rec['CLONING_REF'], dtype=np.int64))
+        return dmc_base.State(confs=group.get('confs')[()], props=state_props,
+                              branching_spec=bs, **_qio.attrs_dict(group))
+
+    def build_proc(self, proc_config):
+        return Proc.from_config({k: v for k, v in proc_config.items()
+                                 if v is not None})
+
+    def build_result(self, state, proc_inst, sampling_data):
+        return ProcResult(state, proc_inst, sampling_data)
+
+    def load_sampling_data(self, group):
+        return _dmc_data.SamplingData.from_hdf5_data(group)
+
+
+AppSpec, CLIApp, get_io_handler = _qcli.make_app_classes(
+    Proc, ProcInput, ModelSysConfSpec, HDF5FileHandler, MODEL_SYS_CONF_TYPE)
+AppMeta = _qcli.AppMeta
+config_loader = _qcfg.Loader(_qio.IO_FILE_HANDLER_TYPES)
+__all__ += ['AppMeta', 'AppSpec', 'CLIApp', 'HDF5FileHandler',
+            'config_loader', 'get_io_handler']

@@ -136,3 +136,42 @@ class Proc:
 
     def exec(self, proc_input: ProcInput):
         return proc_base.exec_vmc(self, proc_input)
+
+
+# ---- result files + command-line application --------------------------
+from ..qmc_exec import cli_app as _qcli, config as _qcfg, io as _qio  # noqa: E402
+from ..qmc_exec.data import vmc as _vmc_data  # noqa: E402
+
+
+@attr.s(auto_attribs=True, frozen=True)
+class HDF5FileHandler(_qio.HDF5FileHandler):
+    """Structured HDF5 files with VMC procedure results
+    (mrbp_qmc/vmc_exec/io.py, qmc_exec/vmc/io.py:13-80)."""
+    sampling_type: t.ClassVar[str] = 'vmc'
+
+    def save_state(self, state, group):
+        group.create_dataset('sys_conf', data=state.sys_conf)
+        group.attrs.update({'wf_abs_log': float(state.wf_abs_log),
+                            'move_stat': int(state.move_stat)})
+
+    def load_state(self, group):
+        return vmc_base.State(sys_conf=group.get('sys_conf')[()],
+                              **_qio.attrs_dict(group))
+
+    def build_proc(self, proc_config):
+        return Proc.from_config({k: v for k, v in proc_config.items()
+                                 if v is not None})
+
+    def build_result(self, state, proc_inst, sampling_data):
+        return ProcResult(state, proc_inst, sampling_data)
+
+    def load_sampling_data(self, group):
+        return _vmc_data.SamplingData.from_hdf5_data(group)
+
+
+AppSpec, CLIApp, get_io_handler = _qcli.make_app_classes(
+    Proc, ProcInput, ModelSysConfSpec, HDF5FileHandler, MODEL_SYS_CONF_TYPE)
+AppMeta = _qcli.AppMeta
+config_loader = _qcfg.Loader(_qio.IO_FILE_HANDLER_TYPES)
+__all__ += ['AppMeta', 'AppSpec', 'CLIApp', 'HDF5FileHandler',
+            'config_loader', 'get_io_handler']

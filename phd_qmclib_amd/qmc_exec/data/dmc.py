@@ -257,3 +257,82 @@ class PropsDataSeries:
 class SamplingData:
     blocks: PropsDataBlocks
     series: t.Optional[PropsDataSeries] = None
+
+
+# ---- HDF5 layout (qmc_exec/data/dmc.py:99-120, 192-211, 581-613, 683-735,
+# 770-793): <group>/totals [, weight_totals]; ss_factor/{fdk_sqr_abs,fdk_real,
+# fdk_imag}/...; blocks/{energy,weight,num_walkers[,density][,ss_factor]} ----
+def _export_weighted(self, group):
+    group.create_dataset('totals', data=self.totals)
+    group.create_dataset('weight_totals', data=self.weight_totals)
+
+
+def _import_weighted(cls, group):
+    return cls(totals=group.get('totals')[()],
+               weight_totals=group.get('weight_totals')[()])
+
+
+def _export_unweighted(self, group):
+    group.create_dataset('totals', data=self.totals)
+
+
+def _import_unweighted(cls, group):
+    return cls(totals=group.get('totals')[()])
+
+
+PropBlocks.hdf5_export = _export_weighted
+PropBlocks.from_hdf5_data = classmethod(_import_weighted)
+UnWeightedPropBlocks.hdf5_export = _export_unweighted
+UnWeightedPropBlocks.from_hdf5_data = classmethod(_import_unweighted)
+
+
+def _ssf_export(self, group):
+    self.fdk_sqr_abs_part.hdf5_export(group.require_group('fdk_sqr_abs'))
+    self.fdk_real_part.hdf5_export(group.require_group('fdk_real'))
+    self.fdk_imag_part.hdf5_export(group.require_group('fdk_imag'))
+
+
+def _ssf_import(cls, group):
+    return cls(SSFPartBlocks.from_hdf5_data(group.get('fdk_sqr_abs')),
+               SSFPartBlocks.from_hdf5_data(group.get('fdk_real')),
+               SSFPartBlocks.from_hdf5_data(group.get('fdk_imag')))
+
+
+SSFBlocks.hdf5_export = _ssf_export
+SSFBlocks.from_hdf5_data = classmethod(_ssf_import)
+
+
+def _blocks_export(self, group):
+    self.energy.hdf5_export(group.require_group('energy'))
+    self.weight.hdf5_export(group.require_group('weight'))
+    self.num_walkers.hdf5_export(group.require_group('num_walkers'))
+    if self.density is not None:
+        self.density.hdf5_export(group.require_group('density'))
+    if self.ss_factor is not None:
+        self.ss_factor.hdf5_export(group.require_group('ss_factor'))
+
+
+def _blocks_import(cls, group):
+    dens, ssf = group.get('density'), group.get('ss_factor')
+    return cls(EnergyBlocks.from_hdf5_data(group.get('energy')),
+               WeightBlocks.from_hdf5_data(group.get('weight')),
+               NumWalkersBlocks.from_hdf5_data(group.get('num_walkers')),
+               None if dens is None else DensityBlocks.from_hdf5_data(dens),
+               None if ssf is None else SSFBlocks.from_hdf5_data(ssf))
+
+
+PropsDataBlocks.hdf5_export = _blocks_export
+PropsDataBlocks.from_hdf5_data = classmethod(_blocks_import)
+
+
+def _sampling_export(self, group):
+    # (the reference does not store the per-step series either)
+    self.blocks.hdf5_export(group.require_group('blocks'))
+
+
+def _sampling_import(cls, group):
+    return cls(PropsDataBlocks.from_hdf5_data(group.get('blocks')))
+
+
+SamplingData.hdf5_export = _sampling_export
+SamplingData.from_hdf5_data = classmethod(_sampling_import)

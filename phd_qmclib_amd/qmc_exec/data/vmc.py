@@ -57,3 +57,55 @@ class PropsDataBlocks:
 class SamplingData:
     blocks: PropsDataBlocks
     series: t.Optional[t.Any] = None
+
+
+# ---- HDF5 layout (qmc_exec/data/vmc.py:44-62, 246-276, 336-373, 408-429):
+# blocks/energy/totals; blocks/ss_factor/{fdk_sqr_abs,fdk_real,fdk_imag}/totals
+_SSF_PARTS = ('fdk_sqr_abs', 'fdk_real', 'fdk_imag')
+
+
+def _prop_export(self, group):
+    group.create_dataset('totals', data=self.totals)
+
+
+def _prop_import(cls, group):
+    return cls(totals=group.get('totals')[()])
+
+
+PropBlocks.hdf5_export = _prop_export
+PropBlocks.from_hdf5_data = classmethod(_prop_import)
+
+
+def _blocks_export(self, group):
+    self.energy.hdf5_export(group.require_group('energy'))
+    if self.ss_factor is not None:
+        ssf_group = group.require_group('ss_factor')
+        tot = np.asarray(self.ss_factor.totals)      # [block, mode, part]
+        for c, name in enumerate(_SSF_PARTS):
+            ssf_group.require_group(name).create_dataset(
+                'totals', data=np.ascontiguousarray(tot[..., c]))
+
+
+def _blocks_import(cls, group):
+    energy = EnergyBlocks.from_hdf5_data(group.get('energy'))
+    ssf_group, ssf = group.get('ss_factor'), None
+    if ssf_group is not None:
+        ssf = PropBlocks(np.stack([ssf_group.get(name).get('totals')[()]
+                                   for name in _SSF_PARTS], axis=-1))
+    return cls(energy, ssf)
+
+
+PropsDataBlocks.hdf5_export = _blocks_export
+PropsDataBlocks.from_hdf5_data = classmethod(_blocks_import)
+
+
+def _sampling_export(self, group):
+    self.blocks.hdf5_export(group.require_group('blocks'))
+
+
+def _sampling_import(cls, group):
+    return cls(PropsDataBlocks.from_hdf5_data(group.get('blocks')))
+
+
+SamplingData.hdf5_export = _sampling_export
+SamplingData.from_hdf5_data = classmethod(_sampling_import)
