@@ -49,6 +49,10 @@ struct DevModel {
     double cphi, sphi;     // cos/sin(k2 r_off)
     double cth, sth;       // cos(k2 L), |sin(k2 L)|
     int sth_sign;          // sign bit of sin(k2 L) (0 or 0x80000000)
+    // short-range variants (pair_core4): angles c_v added to k2 z_own,
+    // v = (no wrap, d > 0), (no wrap, d < 0), (D > L/2), (D < -L/2)
+    double var_cos[4], var_sin[4];
+    double m_k2;           // -k2
     double sin_rm;         // sin(pi rm / L)
     double a_long, b_long; // (pi/L) beta, (pi/L)^2 beta
     double inv_beta;       // 1 / beta
@@ -224,6 +228,7 @@ struct PairConsts {
     double sin_rm, cth, m_k2cphi, sphi, cphi;
     double v_sth, v_k2sphi;       // VGPR-resident
     double half_L, rm, L_minus_rm;
+    double m_k2;
     int sth_sign;
 };
 
@@ -235,6 +240,7 @@ __device__ __forceinline__ PairConsts load_pair_consts(const DevModel &m)
     c.half_L = m.half_L; c.rm = m.rm; c.L_minus_rm = m.L_minus_rm;
     c.v_sth = m.sth; c.v_k2sphi = m.k2sphi;
     c.sth_sign = m.sth_sign;
+    c.m_k2 = m.m_k2;
     asm volatile("" : "+v"(c.v_sth), "+v"(c.v_k2sphi));
     return c;
 }
@@ -301,6 +307,77 @@ __device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
     Yout = Y;
 }
 
+// Short-range pair, four-case form (used for P <= 2).  With the minimum-image
+// separation d = D - w L (w = 0, +1, -1) and s = sgn(d), the pair needs
+//   X = -k2 sin(theta), Y = cos(theta), theta = k2 d - phi s
+//     = (k2 z_own - k2 w L - phi s) - k2 z_partner = A_own(w, s) - k2 z_partner
+// and only four (w, s) combinations exist: D in (0, L/2] -> (0, +),
+// [-L/2, 0) -> (0, -), (L/2, L) -> (+1, -), (-L, -L/2) -> (-1, +).  The own
+// particle carries sin/cos of its four angles A (16 instructions per particle
+// and step); a pair is then 4 instructions in the branch of its case instead
+// of the rotate-by-k2 L / copysign sequence.  With position-sorted lanes
+// nearly every lane of a rotation step is in the same one or two cases.
+struct ShortTab {
+    double s[4], c[4];
+};
+
+__device__ __forceinline__ void make_short_tab(const DevModel &m, double su,
+                                               double cu, ShortTab &st)
+{
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        st.s[v] = fma(su, m.var_cos[v], cu * m.var_sin[v]);
+        st.c[v] = fma(cu, m.var_cos[v], -(su * m.var_sin[v]));
+    }
+}
+
+template <bool ZCLASS>
+__device__ __forceinline__ void pair_core4(const PairConsts &m, const PTab &a,
+                                           const ShortTab &sa, double aks,
+                                           double akc, double za,
+                                           const PTab &b, double zb, double &q,
+                                           double &Yout, bool &isshort,
+                                           unsigned long long &shortmask)
+{
+    double S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
+    double X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    double Y = S;
+    bool wrapped, neg;
+    if (ZCLASS) {
+        const double D = za - zb;
+        const double aD = fabs(D);
+        wrapped = aD > m.half_L;
+        neg = D < 0.0;
+        isshort = (aD < m.rm) | (aD > m.L_minus_rm);
+    } else {
+        wrapped = X < 0.0;                // |z_a - z_b| > L/2
+        neg = S < 0.0;                    // sgn(D) = sgn(sin(pi D / L))
+        isshort = fabs(S) < m.sin_rm;     // min-image r < rm
+    }
+    shortmask = __ballot(isshort);
+    if (isshort) {
+        double xs, ys;
+        // real (exec-masked) branches: as selects the four cases would cost
+        // eight v_cndmask per double pair
+#define QMC_CASE4(v)                                                          \
+        {                                                                     \
+            asm volatile("");                                                 \
+            xs = sa.s[v] * b.cu - sa.c[v] * b.su;                             \
+            ys = sa.c[v] * b.cu + sa.s[v] * b.su;                             \
+        }
+        if (!wrapped) {
+            if (!neg) QMC_CASE4(0) else QMC_CASE4(1)
+        } else {
+            if (!neg) QMC_CASE4(2) else QMC_CASE4(3)
+        }
+#undef QMC_CASE4
+        X = m.m_k2 * xs;
+        Y = ys;
+    }
+    q = pair_div(X, Y);
+    Yout = Y;
+}
+
 // LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of
 // DUP*G*P doubles.  For P = 1 every entry is stored twice (lane g at g and
 // G + g) so a rotated read (g - k) never needs a modulo; for P >= 2 the copy
@@ -337,7 +414,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     double *lS = lds, *lC = lds + ROW, *lSU = lds + 2 * ROW,
            *lCU = lds + 3 * ROW, *lZ = lds + 4 * ROW;
     const int n = m.n;
+    // four-case short-range form while the own tables fit (see pair_core4)
+    constexpr bool FOURCASE = (P <= 2);
     PTab t[PA];
+    ShortTab st4[FOURCASE ? PA : 1];
     double aks[PA], akc[PA];   // a_long * (sin, cos)(pi z / L)
     bool ok[P];
     double kin1[P];          // one-body kinetic + potential (ITH)
@@ -367,6 +447,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 t[a % PA] = ta;
                 aks[a % PA] = m.a_long * ta.s;
                 akc[a % PA] = m.a_long * ta.c;
+                if (FOURCASE) make_short_tab(m, ta.su, ta.cu, st4[a % PA]);
             }
             int i0 = a * DUP * G + gl;
             lS[i0] = ta.s; lC[i0] = ta.c; lSU[i0] = ta.su; lCU[i0] = ta.cu;
@@ -447,8 +528,12 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 if (NPASS == 1) tb = t[b % PA];
                 else QMC_LOAD_OWN(tb, b);
                 double q, Y; bool sh; unsigned long long shm;
-                pair_core<ZCLASS>(pc, ta, aksa, akca, z[a], tb, z[b], q,
-                                  Y, sh, shm);
+                if (FOURCASE)
+                    pair_core4<ZCLASS>(pc, ta, st4[a % PA], aksa, akca, z[a],
+                                       tb, z[b], q, Y, sh, shm);
+                else
+                    pair_core<ZCLASS>(pc, ta, aksa, akca, z[a], tb, z[b], q,
+                                      Y, sh, shm);
                 if (WAVE_COUNT)
                     ns_wave += __popcll(shm);
                 if (!PAD || (ok[a] && ok[b])) {
@@ -488,8 +573,14 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 for (int a = 0; a < PA; ++a) {                                \
                     constexpr int ao_base = (H) * PA;                         \
                     double q, Y; bool sh; unsigned long long shm;            \
-                    pair_core<ZCLASS>(pc, t[a], aks[a], akc[a],               \
-                                      z[ao_base + a], pb, pz, q, Y, sh, shm); \
+                    if (FOURCASE)                                             \
+                        pair_core4<ZCLASS>(pc, t[a], st4[FOURCASE ? a : 0],   \
+                                           aks[a], akc[a], z[ao_base + a],    \
+                                           pb, pz, q, Y, sh, shm);            \
+                    else                                                      \
+                        pair_core<ZCLASS>(pc, t[a], aks[a], akc[a],           \
+                                          z[ao_base + a], pb, pz, q, Y, sh,   \
+                                          shm);                               \
                     /* G = 64: the lower half of the lanes is bits 0..31 */   \
                     if (WAVE_COUNT)                                           \
                         ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \

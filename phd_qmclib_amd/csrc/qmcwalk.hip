@@ -1127,6 +1127,15 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.cth = cos(th);
     d.sth = fabs(sin(th));
     d.sth_sign = sin(th) < 0.0 ? (int)0x80000000u : 0;
+    {
+        // angles added to k2 z_own for the four short-range cases
+        const double ang[4] = { -phi, phi, phi - th, th - phi };
+        for (int v = 0; v < 4; ++v) {
+            d.var_cos[v] = cos(ang[v]);
+            d.var_sin[v] = sin(ang[v]);
+        }
+        d.m_k2 = -d.k2;
+    }
     d.sin_rm = (d.rm >= d.half_L) ? 1.0 : sin(QMC_PI * d.rm / d.L);
     // sin(pi r / L) is flat near r = L/2: classify from positions there
     d.zclass = d.rm > 0.45 * d.L;
