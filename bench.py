@@ -140,12 +140,15 @@ def main():
     # measured HBM traffic per chain-step (rocprofv3 FETCH_SIZE/WRITE_SIZE passes,
     # profiles/r01_traffic.json), scaled to the units of one launch
     traffic = None
+    valu_per_step = None
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fp:
             tj = json.load(fp)
         if n == 64:
             traffic = tj['vmc_step_kernel_bytes_per_chain_step_N64'] * W * \
                 steps_per_launch
+            valu_per_step = tj.get(
+                'vmc_step_kernel_valu_instr_per_chain_step_N64')
     except (OSError, KeyError, ValueError):
         pass
 
@@ -177,6 +180,14 @@ def main():
         },
         'extra': {
             'valu': {'pair_evals_per_s': pair_rate,
+                     # the ceiling that binds: wave64 VALU instructions issued
+                     # (SQ_INSTS_VALU / SQ_WAVES of the rocprofv3 PMC pass,
+                     # profiles/r01_traffic.json) against 1 instruction per 4
+                     # cycles per SIMD, 4 SIMDs x 256 CUs at 2.4 GHz
+                     'instr_per_chain_step': valu_per_step,
+                     'issue_frac': None if valu_per_step is None else
+                     (W * steps_per_launch * valu_per_step /
+                      (launch_ms * 1e-3)) / (1024 * 2.4e9 / 4),
                      'note': 'the path is fp64-VALU bound (SURVEY.md 8d); '
                              'unique pairs N(N-1)/2 per chain-step'},
             'vmc_energy_per_particle': float(tot[0] / tot[2] / n),
