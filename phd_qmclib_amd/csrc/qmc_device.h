@@ -59,7 +59,10 @@ struct DevModel {
     double beta, log_am;
     // one-body (Kronig-Penney)
     double z_a, z_b, k1, kp1, e0, v0, v0d, v0_minus_e0, cf;
+    int uniform_barrier;   // every barrier has the same height v_barrier
+    double v_barrier;
     double k1_2pi;         // k1 * 2 / pi
+    double k1_half;        // k1 / 2
 };
 
 // ---------------------------------------------------------------- RNG ----
@@ -207,14 +210,26 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
         double ch2 = e + ei;                    // 2 cosh
         ldz = m.kp1 * fast_div(e - ei, ch2);
         f1 = 0.5 * ch2;
-        int nc = (int)n_cell;
-        int r = nc % m.defects_sep;
-        if (r < 0) r += m.defects_sep;
-        double v = (r == 0) ? m.v0d : m.v0;
+        double v = m.v_barrier;
+        if (!m.uniform_barrier) {
+            // lattice defects: every defects_sep-th barrier has height v0d
+            // (an integer modulo by a run-time divisor is ~25 instructions,
+            // skipped by the whole wave in the common defect-free case)
+            int nc = (int)n_cell;
+            int r = nc % m.defects_sep;
+            if (r < 0) r += m.defects_sep;
+            v = (r == 0) ? m.v0d : m.v0;
+        }
         kin_pot = fma(ldz, ldz, v - m.v0_minus_e0);
     } else {
-        double sx, cx;
-        sincos_halfpi(m.k1_2pi * (z_cell - 0.5 * m.z_a), sx, cx);
+        // |k1 (z_cell - z_a/2)| < pi/2 (the ground band's cosine has no node
+        // in the well), so half the angle fits the sin/cos kernels without
+        // range reduction or quadrant logic:
+        //   sin x = 2 s c,  cos x = (c - s)(c + s),  s, c = sin, cos(x / 2)
+        double sh, ch;
+        sincos_kernel(m.k1_half * (z_cell - 0.5 * m.z_a), sh, ch);
+        const double sx = 2.0 * sh * ch;
+        const double cx = (ch - sh) * (ch + sh);
         ldz = -m.k1 * fast_div(sx, cx);
         f1 = m.cf * cx;
         kin_pot = fma(ldz, ldz, m.e0);

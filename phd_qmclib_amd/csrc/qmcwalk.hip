@@ -1203,6 +1203,9 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.e0 = p.param_e0;
     d.v0 = p.lattice_depth;
     d.v0d = p.defect_magnitude;
+    d.uniform_barrier = (d.defects_sep == 1 || d.v0d == d.v0) ? 1 : 0;
+    d.v_barrier = (d.defects_sep == 1) ? d.v0d : d.v0;
+    d.k1_half = 0.5 * p.param_k1;
     d.v0_minus_e0 = p.lattice_depth - p.param_e0;
     if (!d.is_free) {
         double sh = sinh(0.5 * sqrt(d.v0 - d.e0) * d.z_b);
