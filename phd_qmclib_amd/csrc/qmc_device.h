@@ -195,21 +195,24 @@ struct PTab {
 };
 
 // One-body factor (mrbp_qmc/model.py:404-464) and lattice potential (:533-551).
-// ldz = f1'/f1; kin_pot = -f1''/f1 + ldz^2 + V(z); f1 > 0 is the factor itself.
+// ldz = f1'/f1; kin_pot = -f1''/f1 + ldz^2 + V(z); the factor itself is
+// f1 * exp(-xoff) > 0 (the barrier's cosh x is returned as (e^{2x} + 1) / 2
+// with xoff = x: the caller needs log f1 only and subtracts xoff there).
 __device__ __forceinline__ void one_body(const DevModel &m, double z,
                                          double &ldz, double &kin_pot,
-                                         double &f1)
+                                         double &f1, double &xoff)
 {
     double n_cell = floor(z);
     double z_cell = z - n_cell;
     if (m.z_a < z_cell) {
-        // barrier: cosh / tanh through one exponential
+        // barrier: tanh x = (e^{2x} - 1) / (e^{2x} + 1), one exponential and
+        // one division; cosh x = (e^{2x} + 1) / 2 * e^{-x}
         double x = m.kp1 * (z_cell - 1.0 + 0.5 * m.z_b);
-        double e = exp_bounded(x);
-        double ei = fast_rcp(e);
-        double ch2 = e + ei;                    // 2 cosh
-        ldz = m.kp1 * fast_div(e - ei, ch2);
-        f1 = 0.5 * ch2;
+        double e2 = exp_bounded(2.0 * x);
+        double den = e2 + 1.0;
+        ldz = m.kp1 * fast_div(e2 - 1.0, den);
+        f1 = 0.5 * den;
+        xoff = x;
         double v = m.v_barrier;
         if (!m.uniform_barrier) {
             // lattice defects: every defects_sep-th barrier has height v0d
@@ -232,6 +235,7 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
         const double cx = (ch - sh) * (ch + sh);
         ldz = -m.k1 * fast_div(sx, cx);
         f1 = m.cf * cx;
+        xoff = 0.0;
         kin_pot = fma(ldz, ldz, m.e0);
     }
 }
@@ -439,7 +443,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     double kin1_sum = 0.0;   // their sum over the own particles (!ITH)
     double prodS = 1.0, prodL = 1.0;   // running products of pair factors (WF)
     double prod1 = 1.0;      // product of the one-body factors (WF)
+    double xoff_sum = 0.0;   // sum of the exponents split off them (one_body)
     int expS = 0, expL = 0;  // binary exponents split off the products
+    int exp1 = 0;            // ... and off the one-body product (P >= 4)
     int nshort = 0, npair = 0;
     // one walker per wavefront and no padding: short pairs are counted with a
     // ballot + scalar popcount (SALU) instead of a per-lane VALU add
@@ -476,12 +482,19 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             aks[a % PA] = 0.0; akc[a % PA] = 0.0;
         }
         if (!m.is_free) {
-            double ldz, kp, f1;
-            one_body(m, z[a], ldz, kp, f1);
+            double ldz, kp, f1, xoff;
+            one_body(m, z[a], ldz, kp, f1, xoff);
             if (ok[a]) {
                 F[a] = ldz;
                 if (ITH) kin1[a] = kp; else kin1_sum += kp;
-                if (WF) prod1 *= f1;
+                if (WF) {
+                    prod1 *= f1;
+                    xoff_sum += xoff;
+                    if (P >= 4) {     // many factors up to e^{2x} / 2 each
+                        exp1 += __builtin_amdgcn_frexp_exp(prod1);
+                        prod1 = __builtin_amdgcn_frexp_mant(prod1);
+                    }
+                }
             }
         }
     }
@@ -694,7 +707,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // long product = prodL / prodS (mantissas; exponents kept apart)
         double lw = log_pos(prod1 * prodS) +
                     m.beta * log_pos(fabs(fast_div(prodL, prodS))) +
-                    LN2 * ((double)expS + m.beta * (double)(expL - expS));
+                    LN2 * ((double)(expS + exp1) +
+                           m.beta * (double)(expL - expS)) -
+                    xoff_sum;
         if (!WAVE_COUNT) lw += (double)nshort * m.log_am;
         logwf = group_sum<G>(lw);
         if (WAVE_COUNT) logwf += (double)ns_wave * m.log_am;
