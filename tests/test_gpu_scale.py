@@ -147,3 +147,43 @@ def test_large_n_sampling_runs():
     out = v.run_block(6)
     assert np.all(np.isfinite(out['sum_energy']))
     v.close(); eng.close()
+
+
+@pytest.mark.parametrize('n', [100, 128, 130, 256, 300, 512])
+def test_large_shapes_trajectories_vs_oracle(oracle, n):
+    """Every lane-group shape above N = 64 -- (64,2), (64,4), (64,8), exact
+    and padded, i.e. the single-copy LDS tables, the two-pass own-particle
+    scheme and the masked variants -- through the VMC and DMC kernels, against
+    the oracle on the same Philox streams."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
+    spec = box(n)
+    m = oracle.model_from_cfc(spec.cfc_spec)
+    eng = ModelEngine(spec.cfc_spec)
+    rng = np.random.RandomState(n)
+    W, ns = 5, 5
+    pos0 = n * rng.random_sample((W, n))
+    v = VmcEnsemble(eng, W, 0.125, rng_seed=12)
+    v.set_state(pos0)
+    out = v.run_block(ns, series=True)
+    matched = 0
+    for c in range(W):
+        wf, en, st, _ = oracle.VmcChain(m, pos0[c], 0.125, seed=12,
+                                        chain=c).run(ns)
+        if np.array_equal(st, out['move_stat'][:, c]):
+            matched += 1
+            assert np.allclose(en, out['energy'][:, c], rtol=1e-9)
+            assert np.allclose(wf, out['wf_abs_log'][:, c], rtol=1e-9)
+    assert matched >= W - 1
+    v.close()
+    d = DmcEnsemble(eng, 5e-4, 16, 12, 0.5, rng_seed=3)
+    d.set_state(np.vstack([pos0, pos0, pos0[:2]]))
+    orc = oracle.DmcEnsemble(m, np.vstack([pos0, pos0, pos0[:2]]), 5e-4, 16,
+                             12, 0.5, seed=3)
+    ser = d.run_block(4)
+    for t in range(4):
+        o = orc.step()
+        assert int(ser.num_walkers[t]) == o.num_walkers, t
+        assert ser.energy[t] == pytest.approx(o.energy, rel=1e-9), t
+        assert ser.ref_energy[t] == pytest.approx(o.ref_energy, rel=1e-9), t
+    d.close()
+    eng.close()
