@@ -389,45 +389,11 @@ __global__ void __launch_bounds__(BLOCK) branch_count_kernel(BranchArgs a)
     branch_count_tile(a, (int)blockIdx.x);
 }
 
-// Exclusive scan of the block totals (single workgroup, serial over chunks;
-// at most maxw / 1024 entries) and the capped population size
-// (qmc_base/dmc.py:638-653).
-__global__ void __launch_bounds__(BLOCK)
-branch_scan_kernel(BranchArgs a, int nblocks)
-{
-    __shared__ long long sh[BLOCK];
-    __shared__ long long carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const long long prev_nw = a.ctl->prev_nw;
-    const int used = (int)((prev_nw + BR_TILE - 1) / BR_TILE);
-    for (int base = 0; base < nblocks; base += BLOCK) {
-        int i = base + threadIdx.x;
-        long long v = (i < used) ? a.block_tot[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        // Hillis-Steele inclusive scan over BLOCK entries
-        for (int off = 1; off < BLOCK; off <<= 1) {
-            long long t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nblocks) a.block_off[i] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == BLOCK - 1) carry += sh[BLOCK - 1];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        long long nw = carry < a.maxw ? carry : a.maxw;
-        a.ctl->nw = nw;
-    }
-}
-
 // Scatter parent indices into the cloning table in parent order, truncated at
 // max_num_walkers; per-block partial sums of the yielded energies
 // E_t = sum_s E_parent(ref[s]) (qmc_base/dmc.py:759-762).
-__device__ __forceinline__ void branch_scatter_tile(const BranchArgs &a, int tile)
+__device__ __forceinline__ void branch_scatter_tile(const BranchArgs &a, int tile,
+                                                    long long tile_off)
 {
     __shared__ long long wtot[BLOCK / 64];
     __shared__ double wsum[BLOCK / 64];
@@ -452,7 +418,7 @@ __device__ __forceinline__ void branch_scatter_tile(const BranchArgs &a, int til
     __syncthreads();
     long long woff = 0;
     for (int i = 0; i < wv; ++i) woff += wtot[i];
-    long long off = a.block_off[tile] + woff + incl - mine;
+    long long off = tile_off + woff + incl - mine;
     double esum = 0.0;
 #pragma unroll
     for (int k = 0; k < BR_ITEMS; ++k) {
@@ -475,9 +441,34 @@ __device__ __forceinline__ void branch_scatter_tile(const BranchArgs &a, int til
     __syncthreads();
 }
 
+// One workgroup per tile of parents.  The tile's offset into the cloning table
+// is the sum of the clone totals of the tiles before it (at most maxw / 1024
+// values, summed here by the workgroup itself: no separate scan launch); the
+// last tile in use also owns the capped population size
+// (qmc_base/dmc.py:638-653).
 __global__ void __launch_bounds__(BLOCK) branch_scatter_kernel(BranchArgs a)
 {
-    branch_scatter_tile(a, (int)blockIdx.x);
+    __shared__ long long part[BLOCK / 64];
+    const int tile = (int)blockIdx.x;
+    const long long prev_nw = a.ctl->prev_nw;
+    const int used = (int)((prev_nw + BR_TILE - 1) / BR_TILE);
+    if (tile >= used) {
+        if (tile == 0 && threadIdx.x == 0) a.ctl->nw = 0;   // extinct
+        return;
+    }
+    long long t = 0;
+    for (int i = threadIdx.x; i < tile; i += BLOCK) t += a.block_tot[i];
+    for (int msk = 1; msk < 64; msk <<= 1) t += __shfl_xor(t, msk, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    long long tile_off = 0;
+    for (int i = 0; i < BLOCK / 64; ++i) tile_off += part[i];
+    if (tile == used - 1 && threadIdx.x == 0) {
+        const long long total = tile_off + a.block_tot[tile];
+        a.ctl->nw = total < a.maxw ? total : a.maxw;
+    }
+    __syncthreads();
+    branch_scatter_tile(a, tile, tile_off);
 }
 
 // Small populations (at most BR_FUSED_TILES tiles of 1024 parents, i.e. the
@@ -505,7 +496,8 @@ branch_fused_kernel(BranchArgs a, double *partial)
         a.ctl->nw = run < a.maxw ? run : a.maxw;
     }
     __syncthreads();
-    for (int tile = 0; tile < used; ++tile) branch_scatter_tile(a, tile);
+    for (int tile = 0; tile < used; ++tile)
+        branch_scatter_tile(a, tile, a.block_off[tile]);
     if (threadIdx.x == 0) {
         double e_t = 0.0;
         for (int i = 0; i < used; ++i) e_t += a.block_esum[i];
@@ -516,11 +508,11 @@ branch_fused_kernel(BranchArgs a, double *partial)
     }
 }
 
-// Sum the per-block energy partials in a fixed order -> this rank's E_t, W_t.
-__global__ void __launch_bounds__(BLOCK)
-dmc_local_sums_kernel(const double *block_esum, DmcCtl *ctl, double *partial)
+// Sum of the per-tile energy partials in a fixed order (one workgroup of
+// BLOCK threads; the same order wherever it is used) -> sh[0].
+__device__ __forceinline__ double sum_block_esum(const double *block_esum,
+                                                 const DmcCtl *ctl, double *sh)
 {
-    __shared__ double sh[BLOCK];
     const long long prev_nw = ctl->prev_nw;
     const int used = (int)((prev_nw + BR_TILE - 1) / BR_TILE);
     double t = 0.0;
@@ -531,6 +523,15 @@ dmc_local_sums_kernel(const double *block_esum, DmcCtl *ctl, double *partial)
         if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
         __syncthreads();
     }
+    return sh[0];
+}
+
+// This rank's E_t, W_t for the external (multi-GPU) reduction.
+__global__ void __launch_bounds__(BLOCK)
+dmc_local_sums_kernel(const double *block_esum, DmcCtl *ctl, double *partial)
+{
+    __shared__ double sh[BLOCK];
+    sum_block_esum(block_esum, ctl, sh);
     if (threadIdx.x == 0) {
         ctl->e_t = sh[0];
         ctl->w_t = (double)ctl->nw;     // unit weights after branching
@@ -648,6 +649,8 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
 struct FinishArgs {
     DmcCtl *ctl;
     const double *total;      // global (E_t, W_t) or null -> local values
+    const double *block_esum; // per-tile partials to sum here (E_t, unit
+                              // weights) or null -> ctl->e_t / w_t are set
     double *ser_e, *ser_w, *ser_ref, *ser_acc;
     unsigned long long *ser_nw;
     long long ser_idx;
@@ -655,12 +658,17 @@ struct FinishArgs {
 };
 
 // E_ref feedback (qmc_base/dmc.py:759-785) + per-step series.
-__global__ void dmc_finish_kernel(FinishArgs a)
+__global__ void __launch_bounds__(BLOCK) dmc_finish_kernel(FinishArgs a)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double sh[BLOCK];
     DmcCtl *c = a.ctl;
-    double e_t = a.total ? a.total[0] : c->e_t;
-    double w_t = a.total ? a.total[1] : c->w_t;
+    double e_sum = 0.0;
+    if (a.block_esum) e_sum = sum_block_esum(a.block_esum, c, sh);
+    if (threadIdx.x != 0) return;
+    double e_t, w_t;
+    if (a.total) { e_t = a.total[0]; w_t = a.total[1]; }
+    else if (a.block_esum) { e_t = e_sum; w_t = (double)c->nw; }
+    else { e_t = c->e_t; w_t = c->w_t; }
     c->total_energy += e_t;
     c->total_weight += w_t;
     double accum = c->total_energy / c->total_weight;
@@ -1636,6 +1644,7 @@ struct qmc_dmc {
     std::vector<long long> u_off, g_off;
     long long tape_step = 0;
     bool stepped = false;        // a step has run since the last set_state
+    bool sums_pending = false;   // E_t partials still to be summed (by finish)
     double global_target = 0.0;
     // estimators (f1)
     qmc_dmc_est_params est;
@@ -1924,17 +1933,19 @@ static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev)
     b.u_tape = ut; b.maxw = d->maxw; b.seed = d->p.rng_seed;
     b.slot0 = d->p.slot0;
     if (d->nblocks <= BR_FUSED_TILES) {
+        d->sums_pending = false;
         hipLaunchKernelGGL(branch_fused_kernel, dim3(1), dim3(BLOCK), 0,
                            e->stream, b, partial_dev);
     } else {
         hipLaunchKernelGGL(branch_count_kernel, dim3(d->nblocks), dim3(BLOCK),
                            0, e->stream, b);
-        hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(BLOCK), 0,
-                           e->stream, b, d->nblocks);
         hipLaunchKernelGGL(branch_scatter_kernel, dim3(d->nblocks),
                            dim3(BLOCK), 0, e->stream, b);
-        hipLaunchKernelGGL(dmc_local_sums_kernel, dim3(1), dim3(BLOCK), 0,
-                           e->stream, d->block_esum, d->ctl, partial_dev);
+        // single GPU: the finish kernel sums the partials itself
+        d->sums_pending = partial_dev == nullptr;
+        if (partial_dev)
+            hipLaunchKernelGGL(dmc_local_sums_kernel, dim3(1), dim3(BLOCK), 0,
+                               e->stream, d->block_esum, d->ctl, partial_dev);
     }
     HIP_TRY(hipGetLastError());
     EvolveArgs a;
@@ -1959,13 +1970,15 @@ static int dmc_enqueue_finish(qmc_dmc *d, const double *total_dev,
     qmc_engine *e = d->eng;
     FinishArgs f;
     f.ctl = d->ctl; f.total = total_dev;
+    f.block_esum = (!total_dev && d->sums_pending) ? d->block_esum : nullptr;
     const bool rec = ser_idx >= 0;
     f.ser_e = rec ? d->ser_e : nullptr; f.ser_w = d->ser_w;
     f.ser_ref = d->ser_ref; f.ser_acc = d->ser_acc; f.ser_nw = d->ser_nw;
     f.ser_idx = ser_idx;
     f.kappa = d->p.num_walkers_control_factor; f.dt = d->p.time_step;
     f.target = d->global_target;
-    hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(64), 0, e->stream, f);
+    hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(BLOCK), 0, e->stream,
+                       f);
     HIP_TRY(hipGetLastError());
     d->cur = 1 - d->cur;          // children become the parents
     d->stepped = true;
