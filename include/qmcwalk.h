@@ -161,6 +161,12 @@ int qmc_vmc_run_block(qmc_vmc *v, int64_t nyield, double *sum_energy,
  * every host-facing call un-permutes).  Symmetric functions of a
  * configuration can be evaluated on these buffers directly. */
 int qmc_vmc_state_dev(qmc_vmc *v, double **pos, double **wf);
+/* Static structure factor parts of the CURRENT configurations summed over the
+ * chains: out[num_modes][3] = sum_w (|rho_m|^2, Re rho_m, Im rho_m),
+ * rho_m = sum_i exp(i 2 pi m z_i / L)  (the per-step quantity of
+ * qmc_base/jastrow/vmc.py:304-351, evaluated for a whole ensemble in one
+ * launch).  Host buffer; synchronous. */
+int qmc_vmc_ssf(qmc_vmc *v, int32_t num_modes, double *out);
 /* Device addresses of the per-chain block sums of the last block
  * (sum_e[W], sum_e2[W], n_acc[W]) for on-device reductions / collectives. */
 int qmc_vmc_block_sums_dev(qmc_vmc *v, double **sum_e, double **sum_e2,

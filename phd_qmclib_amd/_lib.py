@@ -81,6 +81,7 @@ SIGNATURES = {
     'qmc_vmc_destroy': (None, [_vp]),
     'qmc_vmc_set_state': (C.c_int, [_vp, _dp]),
     'qmc_vmc_get_state': (C.c_int, [_vp, _dp, _dp, _dp]),
+    'qmc_vmc_ssf': (C.c_int, [_vp, C.c_int32, _dp]),
     'qmc_vmc_run_block': (C.c_int, [_vp, C.c_int64, _dp, _dp, _i64p, _dp, _dp,
                                     _u8p, _dp]),
     'qmc_vmc_state_dev': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),

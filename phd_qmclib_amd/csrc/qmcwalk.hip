@@ -771,7 +771,9 @@ __global__ void __launch_bounds__(BLOCK) dmc_ssf_mfma_kernel(EstArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *X = smem + (size_t)wave * S::WAVE_DOUBLES;   // F_a (rows of D)
     double *Y = X + S::ROWS * RS;                        // E_b (columns of D)
-    const long long nw = a.ctl->nw;
+    // (VMC ensembles use the kernel without a cloning table: ref = identity,
+    // population = maxw chains)
+    const long long nw = a.ctl ? a.ctl->nw : a.maxw;
     const long long wstride = (long long)gridDim.x * (BLOCK / 64);
     const int quad = lane >> 4, idx = lane & 15;
     // modes owned by this lane when the results are handed out
@@ -785,7 +787,7 @@ __global__ void __launch_bounds__(BLOCK) dmc_ssf_mfma_kernel(EstArgs a)
     const bool accumulate = !a.pure || a.step_idx < a.pfw;
     for (long long s = (long long)blockIdx.x * (BLOCK / 64) + wave; s < nw;
          s += wstride) {
-        const long long par = a.ref[s];
+        const long long par = a.ref ? a.ref[s] : s;
         double re[NM], im[NM];
 #pragma unroll
         for (int r = 0; r < NM; ++r) re[r] = im[r] = 0.0;
@@ -1429,6 +1431,8 @@ struct qmc_vmc {
     long long tape_steps = 0, tape_used = 0;
     unsigned int step = 0;
     int yield_initial = 1;
+    double *ssf_partial = nullptr, *ssf_out = nullptr;   // qmc_vmc_ssf scratch
+    int ssf_cap = 0;
 };
 
 extern "C" int qmc_vmc_create(qmc_engine *e, const qmc_vmc_params *p,
@@ -1457,6 +1461,8 @@ extern "C" void qmc_vmc_destroy(qmc_vmc *v)
     if (!v) return;
     hipSetDevice(v->eng->device);
     hipFree(v->pos); hipFree(v->label); hipFree(v->wf); hipFree(v->ecarry);
+    if (v->ssf_partial) hipFree(v->ssf_partial);
+    if (v->ssf_out) hipFree(v->ssf_out);
     hipFree(v->sum_e); hipFree(v->sum_e2); hipFree(v->n_acc);
     if (v->tape) hipFree(v->tape);
     delete v;
@@ -1538,6 +1544,54 @@ extern "C" int qmc_vmc_state_dev(qmc_vmc *v, double **pos, double **wf)
     if (!v) return fail("null argument");
     if (pos) *pos = v->pos;
     if (wf) *wf = v->wf;
+    return 0;
+}
+
+// Static structure factor parts of the current configurations, summed over
+// the chains: out[m] = sum_w (|rho_m|^2, Re rho_m, Im rho_m), m < num_modes
+// (qmc_base/jastrow/vmc.py:304-351 evaluates them per step of one chain; an
+// ensemble gets them in one launch of the matrix-core kernel).
+extern "C" int qmc_vmc_ssf(qmc_vmc *v, int32_t num_modes, double *out)
+{
+    if (!v || !out) return fail("qmc_vmc_ssf: null argument");
+    if (num_modes <= 0 || num_modes > EST_MAXK)
+        return fail("qmc_vmc_ssf: num_modes must be in [1, 256]");
+    qmc_engine *e = v->eng;
+    HIP_TRY(hipSetDevice(e->device));
+    const int M = num_modes;
+    if (M > v->ssf_cap) {
+        if (v->ssf_partial) { hipFree(v->ssf_partial); hipFree(v->ssf_out); }
+        v->ssf_partial = v->ssf_out = nullptr;
+        if (dev_alloc(&v->ssf_partial, (size_t)EST_BLOCKS * M * 3) ||
+            dev_alloc(&v->ssf_out, (size_t)M * 3))
+            return 1;
+        v->ssf_cap = M;
+    }
+    EstArgs a;
+    a.ppos = v->pos; a.ref = nullptr; a.ctl = nullptr;
+    a.aux_prev = nullptr; a.aux_act = nullptr; a.partial = v->ssf_partial;
+    a.maxw = v->W; a.step_idx = 0; a.pfw = 0; a.n = e->dm.n; a.K = M;
+    a.pure = 0; a.scale = 4.0 / e->dm.L;
+    if (M <= 64) {
+        const size_t lds = (size_t)(BLOCK / 64) * SsfShape<8>::WAVE_DOUBLES *
+                           sizeof(double);
+        allow_lds(dmc_ssf_mfma_kernel<8>, lds);
+        hipLaunchKernelGGL(dmc_ssf_mfma_kernel<8>, dim3(EST_BLOCKS),
+                           dim3(BLOCK), lds, e->stream, a);
+    } else {
+        const size_t lds = (size_t)(BLOCK / 64) * SsfShape<16>::WAVE_DOUBLES *
+                           sizeof(double);
+        allow_lds(dmc_ssf_mfma_kernel<16>, lds);
+        hipLaunchKernelGGL(dmc_ssf_mfma_kernel<16>, dim3(EST_BLOCKS),
+                           dim3(BLOCK), lds, e->stream, a);
+    }
+    hipLaunchKernelGGL(est_reduce_kernel, dim3((M * 3 + 31) / 32), dim3(256), 0,
+                       e->stream, v->ssf_partial, EST_BLOCKS, M * 3, 1.0,
+                       v->ssf_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, v->ssf_out, (size_t)M * 3 * sizeof(double),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 

@@ -192,6 +192,14 @@ class VmcEnsemble:
             raise ValueError('pos must have shape (num_chains, boson_number)')
         check(self._lib.qmc_vmc_set_state(self._h, ptr(pos)))
 
+    def ssf_parts(self, num_modes: int) -> np.ndarray:
+        """Mean over the chains of the S(k) parts (|rho_k|^2, Re rho_k,
+        Im rho_k) of the current configurations, k_m = 2 pi m / L,
+        m < num_modes -> [num_modes, 3]."""
+        out = np.zeros((int(num_modes), 3))
+        check(self._lib.qmc_vmc_ssf(self._h, int(num_modes), ptr(out)))
+        return out / self.num_chains
+
     def get_state(self):
         """-> (pos[W, N], wf_abs_log[W], energy_carry[W])"""
         W, n = self.num_chains, self.num_particles

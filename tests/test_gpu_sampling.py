@@ -347,3 +347,26 @@ def test_vmc_ndf_gaussian_proposal(oracle, golden_params):
     assert np.allclose(en, blk.iter_props.energy, rtol=1e-9)
     assert np.allclose(wf, blk.iter_props.wf_abs_log, rtol=1e-9)
     assert 0.2 < blk.accept_rate <= 1.0
+
+
+@pytest.mark.parametrize('n,modes', [(16, 8), (64, 64), (64, 130)])
+def test_vmc_ensemble_ssf_on_device(n, modes):
+    """f2: S(k) parts of a whole VMC ensemble in one launch (matrix-core
+    kernel) against numpy on the ensemble's configurations."""
+    from phd_qmclib_amd.engine import ModelEngine, VmcEnsemble
+    spec = box(n)
+    eng = ModelEngine(spec.cfc_spec)
+    W = 700
+    v = VmcEnsemble(eng, W, 0.125, rng_seed=9)
+    v.set_state(n * np.random.RandomState(n).random_sample((W, n)))
+    v.run_block(20, sums=False)
+    got = v.ssf_parts(modes)
+    z = v.get_state()[0]
+    k = 2 * pi * np.arange(modes) / n
+    ph = np.exp(1j * k[None, :, None] * z[:, None, :]).sum(axis=2)
+    ref = np.stack([(np.abs(ph) ** 2).mean(0), ph.real.mean(0),
+                    ph.imag.mean(0)], axis=1)
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    # S(k = 0) parts: N^2, N, 0
+    assert got[0, 0] == pytest.approx(n * n) and got[0, 1] == pytest.approx(n)
+    v.close(); eng.close()

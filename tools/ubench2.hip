@@ -195,6 +195,22 @@ KERNEL(k_mov64_dpp, asm volatile(
     "v_mov_b64_dpp %6, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_mov_b64_dpp %7, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
     : D64 : "v"(s0));)
 
+KERNEL(k_mad_u64_u32, {
+    unsigned long long q0; unsigned long long q1; unsigned long long q2; unsigned long long q3;
+    asm volatile(
+    "v_mad_u64_u32 %0, vcc, %4, %5, 0\n v_mad_u64_u32 %1, vcc, %4, %5, 0\n v_mad_u64_u32 %2, vcc, %4, %5, 0\n v_mad_u64_u32 %3, vcc, %4, %5, 0\n"
+    "v_mad_u64_u32 %0, vcc, %4, %5, 0\n v_mad_u64_u32 %1, vcc, %4, %5, 0\n v_mad_u64_u32 %2, vcc, %4, %5, 0\n v_mad_u64_u32 %3, vcc, %4, %5, 0\n"
+    : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(i0), "v"(i1) : "vcc");
+    e0 += (int)q0 + (int)q1 + (int)q2 + (int)q3; })
+KERNEL(k_log_f32, asm volatile(
+    "v_log_f32 %0, %8\n v_log_f32 %1, %8\n v_log_f32 %2, %8\n v_log_f32 %3, %8\n"
+    "v_log_f32 %4, %8\n v_log_f32 %5, %8\n v_log_f32 %6, %8\n v_log_f32 %7, %8\n"
+    : D32 : "v"(i0));)
+KERNEL(k_cvt_f64_u32, asm volatile(
+    "v_cvt_f64_u32 %0, %8\n v_cvt_f64_u32 %1, %8\n v_cvt_f64_u32 %2, %8\n v_cvt_f64_u32 %3, %8\n"
+    "v_cvt_f64_u32 %4, %8\n v_cvt_f64_u32 %5, %8\n v_cvt_f64_u32 %6, %8\n v_cvt_f64_u32 %7, %8\n"
+    : D64 : "v"(i0));)
+
 template <typename K>
 int run(K kern, const char *name, int wavesPerSimd, int opsPerIter)
 {
@@ -225,7 +241,7 @@ int main()
         R(k_add32, 8) R(k_lshl, 8) R(k_bfi, 8) R(k_mov32, 8) R(k_mov64, 8) R(k_rndne, 8) R(k_floor, 8)
         R(k_fract, 8) R(k_frexpm, 8) R(k_rsq, 8) R(k_frexpe, 8) R(k_cvti, 8) R(k_cvtd, 8) R(k_ldexp, 8)
         R(k_cmp_sgpr, 8) R(k_fma_sgpr, 8) R(k_fma_lit, 8) R(k_dsread128, 8) R(k_dsread2st64, 8) R(k_dsread64, 8)
-        R(k_cnd_e64_vcc, 8) R(k_cmp_cnd_vcc, 8) R(k_cmp_cnd_sgpr, 8) R(k_cmp_vcc, 8) R(k_ds_add_f64, 8) R(k_ds_add_f64_same, 8) R(k_ds_write_b64, 8) R(k_readlane, 8) R(k_max64, 8) R(k_and_or, 8) R(k_dpp_mov_ror, 8) R(k_dpp_mov_rowshr, 8) R(k_mov64_dpp, 8)
+        R(k_cnd_e64_vcc, 8) R(k_cmp_cnd_vcc, 8) R(k_cmp_cnd_sgpr, 8) R(k_cmp_vcc, 8) R(k_ds_add_f64, 8) R(k_ds_add_f64_same, 8) R(k_ds_write_b64, 8) R(k_readlane, 8) R(k_max64, 8) R(k_and_or, 8) R(k_dpp_mov_ror, 8) R(k_dpp_mov_rowshr, 8) R(k_mov64_dpp, 8) R(k_mad_u64_u32, 8) R(k_log_f32, 8) R(k_cvt_f64_u32, 8)
     }
     return 0;
 }
