@@ -282,6 +282,16 @@ class EnsembleSampling:
         """Current positions of every chain, [W, N] (VMC -> DMC hand-off)."""
         return self.ensemble.get_state()[0]
 
+    def ssf(self, num_modes: int):
+        """Static structure factor of the ensemble's current configurations,
+        S(k_m) = (<|rho_k|^2> - <Re rho_k>^2 - <Im rho_k>^2) / N with the
+        averages over the chains (qmc_exec/data/vmc.py SSFBlocks.mean), and
+        the momenta k_m = 2 pi m / L -> (momenta[M], ssf[M])."""
+        parts = self.ensemble.ssf_parts(num_modes)
+        n, L = self.model_spec.boson_number, self.model_spec.supercell_size
+        ssf = (parts[:, 0] - parts[:, 1] ** 2 - parts[:, 2] ** 2) / n
+        return np.arange(int(num_modes)) * 2 * pi / L, ssf
+
     def close(self):
         self.ensemble.close()
         self.engine.close()

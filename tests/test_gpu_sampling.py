@@ -408,3 +408,20 @@ def test_lieb_liniger_known_answer():
     assert res[True] < e_vmc
     assert abs(res[False] - 1.0504) < 0.015, res
     v.close(); eng.close()
+
+
+def test_ensemble_sampling_ssf():
+    """EnsembleSampling.ssf: S(k) of the box from 2048 equilibrated chains is
+    0 at k = 0, positive elsewhere and tends to 1 at large k."""
+    from phd_qmclib_amd import mrbp_qmc
+    spec = box(16)
+    smp = mrbp_qmc.vmc.EnsembleSampling(spec, 0.125, 2048, rng_seed=5)
+    smp.init_random(seed=1)
+    next(smp.blocks(400))
+    k, ssf = smp.ssf(48)
+    assert k[1] == pytest.approx(2 * pi / 16)
+    assert abs(ssf[0]) < 1e-9
+    assert np.all(ssf[1:] > 0) and np.all(ssf[1:] < 3)
+    # far beyond the lattice's Bragg peak (k = 2 pi) the gas looks uncorrelated
+    assert abs(ssf[40:].mean() - 1.0) < 0.15
+    smp.close()
