@@ -181,7 +181,10 @@ def gen_vmc_tape():
     out = {}
     cases = [('box8', 0.125, 3, 96), ('box16', 0.125, 2, 128),
              ('free16', 0.125, 2, 64), ('deep16', 0.125, 2, 64),
-             ('defect24', 0.3, 2, 48)]
+             ('defect24', 0.3, 2, 48),
+             # the benchmarked lane-group shape (one wavefront per walker) and
+             # the position-classified pairs (r_m = L/2) on a two-particle shape
+             ('box64', 0.125, 2, 24), ('odd24', 0.3, 2, 32)]
     for tag, spread, nblocks, ns in cases:
         spec = mrbp_qmc.Spec(**SPECS[tag])
         np.random.seed(4242)
@@ -221,7 +224,9 @@ def gen_dmc_tape():
              ('free16', 'free16', 1e-3, 12, 16, 0.5, 24, 16),
              # target above the cap: the population grows into max_num_walkers
              # and the branching loop truncates (qmc_base/dmc.py:638-651)
-             ('cap8', 'box8', 2e-3, 40, 22, 0.5, 40, 20)]
+             ('cap8', 'box8', 2e-3, 40, 22, 0.5, 40, 20),
+             ('box64', 'box64', 6.25e-4, 6, 8, 0.5, 10, 6),
+             ('odd24', 'odd24', 1e-3, 8, 10, 0.5, 12, 8)]
     for tag, stag, dt, target, maxw, kappa, steps, n_ini in cases:
         spec = mrbp_qmc.Spec(**SPECS[stag])
         np.random.seed(1717)

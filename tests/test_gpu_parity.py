@@ -93,7 +93,7 @@ def test_evaluate_ragged_batch(engines, oracle, golden_params):
 
 
 @pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'deep16',
-                                 'defect24'])
+                                 'defect24', 'box64', 'odd24'])
 def test_vmc_tape_replay(engines, golden_vmc_tape, tag):
     """Replay of the reference's recorded rand() stream: identical accept /
     reject sequence, log-psi and energy series, block by block."""
@@ -119,7 +119,8 @@ def test_vmc_tape_replay(engines, golden_vmc_tape, tag):
     ens.close()
 
 
-@pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'cap8'])
+@pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'cap8', 'box64',
+                                 'odd24'])
 def test_dmc_tape_replay(engines, golden_dmc_tape, tag):
     """Replay of the reference's rand()/normal() streams through the device
     branching scan + propagation: population sizes and cloning tables exact,

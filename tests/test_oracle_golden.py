@@ -26,7 +26,7 @@ def test_kernels_bit_exact(oracle, golden_params, golden_kernels, tag):
 
 
 @pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'deep16',
-                                 'defect24'])
+                                 'defect24', 'box64', 'odd24'])
 def test_vmc_tape_replay(oracle, golden_params, golden_vmc_tape, tag):
     """Replays the reference's recorded rand() stream through the oracle's
     Metropolis chain: per-step log-psi, move status and energy must match
@@ -51,7 +51,8 @@ def test_vmc_tape_replay(oracle, golden_params, golden_vmc_tape, tag):
     assert np.array_equal(ch.pos, g[tag + '/last_pos'])
 
 
-@pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'cap8'])
+@pytest.mark.parametrize('tag', ['box8', 'box16', 'free16', 'cap8', 'box64',
+                                 'odd24'])
 def test_dmc_tape_replay(oracle, golden_params, golden_dmc_tape, tag):
     """Replays the reference's rand()/normal() streams through the oracle's
     DMC generator: branching table, per-step scalars, yielded walkers
