@@ -98,6 +98,28 @@ class OracleShard:
         return sorted(float(x) for x in en[:nw])
 
 
+class OracleVmcShard:
+    """`vmc.EnsembleSampling` look-alike (attribute `.ensemble` with
+    `run_block`) over the oracle's chain ensemble."""
+
+    def __init__(self, orc, model, pos, move_spread, seed, first_chain):
+        self.orc, self.model = orc, model
+        self.pos = np.array(pos, dtype=np.float64, order='C')     # own copy
+        self.wf = np.array([orc.wf_abs_log(model, p) for p in self.pos])
+        self.ec = np.zeros(len(self.pos))
+        self.spread, self.seed, self.chain0 = move_spread, seed, first_chain
+        self.step = 0
+        self.ensemble = self
+
+    def run_block(self, ns):
+        se, se2, na = self.orc.vmc_ensemble(
+            self.model, self.pos, self.wf, self.ec, self.spread, self.seed,
+            ns, step0=self.step, yield_initial=self.step == 0,
+            chain0=self.chain0, nthreads=1)
+        self.step += ns - (1 if self.step == 0 else 0)
+        return dict(sum_energy=se, sum_energy2=se2, num_accepted=na)
+
+
 def main():
     rank, world, port, out_dir = (int(sys.argv[1]), int(sys.argv[2]),
                                   sys.argv[3], sys.argv[4])
@@ -130,6 +152,24 @@ def main():
     ser = dd.run_block(10)
     res.update(series=ser.tolist(), counts_end=dd.global_counts(),
                walkers_moved=dd.walkers_moved)
+    # VMC: chains sharded by global index; the global block statistics must
+    # not depend on how many ranks hold them
+    from phd_qmclib_amd.dist import DistributedVmc
+    all_pos = n * np.random.RandomState(55).random_sample((12, n))
+    per = 12 // world
+    dv = DistributedVmc(
+        lambda first: OracleVmcShard(orc, m, all_pos[first:first + per],
+                                     0.125, 21, first), per, device='cpu')
+    res['vmc'] = [dv.run_block(16), dv.run_block(16)]
+    if rank == 0:
+        whole = OracleVmcShard(orc, m, all_pos, 0.125, 21, 0)
+        tot = []
+        for _ in range(2):
+            o = whole.run_block(16)
+            tot.append(dict(
+                energy_mean=float(o['sum_energy'].sum() / (12 * 16)),
+                accept_rate=float(o['num_accepted'].sum() / (12 * 16))))
+        res['vmc_single'] = tot
     with open(os.path.join(out_dir, f'rank{rank}.json'), 'w') as fp:
         json.dump(res, fp)
     dist.destroy_process_group()

@@ -64,3 +64,11 @@ def test_two_rank_dmc_gloo(tmp_path, oracle):
     e_per = s0[:, 0] / s0[:, 1] / 8
     assert np.all((e_per > 10) & (e_per < 25))
     assert sum(r0['counts_end']) == int(s0[-1, 1])
+    # VMC: both ranks hold the same global block statistics, equal to those
+    # of one process running all twelve chains (Philox stream = chain index)
+    assert r0['vmc'] == r1['vmc']
+    for blk, single in zip(r0['vmc'], r0['vmc_single']):
+        assert blk['num_samples'] == 12 * 16
+        assert blk['energy_mean'] == pytest.approx(single['energy_mean'],
+                                                   rel=1e-13)
+        assert blk['accept_rate'] == single['accept_rate']
