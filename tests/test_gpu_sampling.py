@@ -425,3 +425,42 @@ def test_ensemble_sampling_ssf():
     # far beyond the lattice's Bragg peak (k = 2 pi) the gas looks uncorrelated
     assert abs(ssf[40:].mean() - 1.0) < 0.15
     smp.close()
+
+
+def test_vmc_n64_statistics_vs_oracle(oracle):
+    """The north-star gate at the benchmarked size (N = 64, where the reference
+    itself is too slow to sample): block-averaged energy and acceptance of the
+    device ensemble against the pinned CPU oracle run with independent chains,
+    within 2.5 sigma of the combined Monte Carlo error (fixed seeds)."""
+    from phd_qmclib_amd.engine import ModelEngine, VmcEnsemble
+    spec = box(64)
+    m = oracle.model_from_cfc(spec.cfc_spec)
+    burn, ns = 300, 500
+    # oracle: 384 chains
+    Wo = 384
+    pos = 64 * np.random.RandomState(8).random_sample((Wo, 64))
+    wf = np.array([oracle.wf_abs_log(m, p) for p in pos])
+    ec = np.zeros(Wo)
+    oracle.vmc_ensemble(m, pos, wf, ec, 0.125, 77, burn, yield_initial=True)
+    se, _, na = oracle.vmc_ensemble(m, pos, wf, ec, 0.125, 77, ns,
+                                    step0=burn)
+    eo = se / ns / 64
+    # device: 8192 chains, other seed
+    eng = ModelEngine(spec.cfc_spec)
+    Wg = 8192
+    v = VmcEnsemble(eng, Wg, 0.125, rng_seed=1234)
+    v.set_state(64 * np.random.RandomState(9).random_sample((Wg, 64)))
+    v.run_block(burn, sums=False)
+    out = v.run_block(ns)
+    eg = out['sum_energy'] / ns / 64
+    z = (eg.mean() - eo.mean()) / np.sqrt(eg.var(ddof=1) / Wg +
+                                          eo.var(ddof=1) / Wo)
+    assert abs(z) < 2.5, (z, eg.mean(), eo.mean())
+    acc_g = out['num_accepted'] / ns
+    acc_o = na / ns
+    za = (acc_g.mean() - acc_o.mean()) / np.sqrt(acc_g.var(ddof=1) / Wg +
+                                                 acc_o.var(ddof=1) / Wo)
+    assert abs(za) < 2.5, (za, acc_g.mean(), acc_o.mean())
+    # the chain-to-chain spread itself is the same distribution
+    assert eg.std(ddof=1) == pytest.approx(eo.std(ddof=1), rel=0.15)
+    v.close(); eng.close()
