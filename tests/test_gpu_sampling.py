@@ -464,3 +464,48 @@ def test_vmc_n64_statistics_vs_oracle(oracle):
     # the chain-to-chain spread itself is the same distribution
     assert eg.std(ddof=1) == pytest.approx(eo.std(ddof=1), rel=0.15)
     v.close(); eng.close()
+
+
+def test_dmc_n64_statistics_vs_oracle(oracle):
+    """Same gate for DMC at N = 64: independent ensembles of 128 walkers (same
+    population, hence the same population-control bias) on the device and in
+    the oracle; time-averaged E/N and mean population agree (pooled t-test over
+    the runs, |t| < 3.4 at 12 degrees of freedom)."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    spec = box(64)
+    m = oracle.model_from_cfc(spec.cfc_spec)
+    eng = ModelEngine(spec.cfc_spec)
+    dt, target, maxw, eq, ns = 1e-3, 128, 160, 200, 300
+    start = 64 * np.random.RandomState(3).random_sample((target, 64))
+
+    def dev_run(seed):
+        d = DmcEnsemble(eng, dt, maxw, target, 0.5, rng_seed=seed)
+        d.set_state(start)
+        d.run_block(eq, read=False)
+        s = d.run_block(ns)
+        d.close()
+        return s.energy.sum() / s.weight.sum() / 64, s.num_walkers.mean()
+
+    def orc_run(seed):
+        o = oracle.DmcEnsemble(m, start, dt, maxw, target, 0.5, seed=seed,
+                               nthreads=oracle.max_threads())
+        for _ in range(eq):
+            o.step()
+        e = w = nw = 0.0
+        for _ in range(ns):
+            y = o.step()
+            e += y.energy; w += y.weight; nw += y.num_walkers
+        return e / w / 64, nw / ns
+
+    dev = np.array([dev_run(100 + k) for k in range(10)])
+    orc = np.array([orc_run(200 + k) for k in range(4)])
+    for col, name in ((0, 'E/N'), (1, '<nw>')):
+        # same process on both sides -> pooled run-to-run variance (12 dof)
+        nd, no = len(dev), len(orc)
+        pooled = ((nd - 1) * dev[:, col].var(ddof=1) +
+                  (no - 1) * orc[:, col].var(ddof=1)) / (nd + no - 2)
+        t = (dev[:, col].mean() - orc[:, col].mean()) / np.sqrt(
+            pooled * (1 / nd + 1 / no))
+        assert abs(t) < 3.4, (name, t, dev[:, col], orc[:, col])
+    assert 14.5 < dev[:, 0].mean() < 16.5
+    eng.close()
