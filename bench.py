@@ -119,6 +119,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # spread of the launch time (SURVEY.md 8d asks for median and min): a few
+    # more chunks, each bracketed by its own HIP events, outside the timed region
+    chunk_ms = []
+    for _ in range(6):
+        eng.timer_start()
+        vmc.run_block(args.block, sums=False)
+        chunk_ms.append(eng.timer_stop() / args.block)
+    chunk_ms.sort()
+
     # block estimators of the last block (global reduction over ranks)
     se_ptr, se2_ptr, na_ptr = vmc.block_sums_dev()
     res = vmc.run_block(args.block, sums=True)
@@ -190,6 +199,8 @@ def main():
                       (launch_ms * 1e-3)) / (1024 * 2.4e9 / 4),
                      'note': 'the path is fp64-VALU bound (SURVEY.md 8d); '
                              'unique pairs N(N-1)/2 per chain-step'},
+            'launch_ms_min': chunk_ms[0],
+            'launch_ms_median': 0.5 * (chunk_ms[2] + chunk_ms[3]),
             'vmc_energy_per_particle': float(tot[0] / tot[2] / n),
             'vmc_accept_rate': float(tot[1] / tot[2]),
         },
