@@ -636,7 +636,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                     if (ITH) KT[b] = __shfl(KT[b], src, 64);                  \
                 }                                                             \
             }                                                                 \
-            if (WF && (((k) & 7) == 0 || P > 1)) {                            \
+            /* P = 1: 16 factors between folds, each >= sin(pi rm / L) or   \
+               cos(k2 rm - phi): no underflow for any admissible model */     \
+            if (WF && (((k) & 15) == 0 || P > 1)) {                           \
                 QMC_FOLD(prodS, expS);                                        \
                 QMC_FOLD(prodL, expL);                                        \
             }                                                                 \
