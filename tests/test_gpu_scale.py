@@ -187,3 +187,44 @@ def test_large_shapes_trajectories_vs_oracle(oracle, n):
         assert ser.ref_energy[t] == pytest.approx(o.ref_energy, rel=1e-9), t
     d.close()
     eng.close()
+
+
+def test_random_specs_all_shapes_vs_oracle(oracle):
+    """Differential test over random models at random sizes up to 512 (every
+    lane-group shape, exact and padded, both pair classifiers): evaluate on
+    the device against the oracle, 2e-11 relative per configuration."""
+    from phd_qmclib_amd.engine import ModelEngine
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    rng = np.random.RandomState(424242)
+    done = 0
+    sizes = [2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 255,
+             256, 257, 400, 511, 512]
+    while done < 40:
+        n = int(rng.choice(sizes)) if done < 30 else int(rng.randint(2, 513))
+        L = float(np.round(n * rng.uniform(0.7, 1.8), 3))
+        kw = dict(lattice_depth=float(rng.choice([0.0, rng.uniform(1, 120)])),
+                  lattice_ratio=float(np.round(rng.uniform(0.2, 3.0), 3)),
+                  interaction_strength=float(10 ** rng.uniform(-1, 1.5)),
+                  boson_number=n, supercell_size=L,
+                  tbf_contact_cutoff=float(L * rng.uniform(0.01, 0.494)))
+        try:
+            spec = Spec(**kw)
+            cfc = spec.cfc_spec
+        except ValueError:
+            continue
+        m = oracle.model_from_cfc(cfc)
+        eng = ModelEngine(cfc)
+        pos = L * rng.random_sample((3, n))
+        pos[2] = np.sort(pos[2])            # an ordered configuration too
+        out = eng.evaluate(pos)
+        eng.close()
+        wf, en, ie, fd = oracle.evaluate_set(m, pos)
+        for name, got, ref in (('wf', out.wf_abs_log, wf), ('E', out.energy, en),
+                               ('ith', out.ith_energy, ie),
+                               ('drift', out.drift, fd)):
+            scale = np.maximum(1.0, np.abs(ref).reshape(3, -1).max(1))
+            if name in ('wf', 'E'):
+                scale = np.maximum(scale, np.abs(ie).max(1))
+            err = np.abs(got - ref).reshape(3, -1).max(1) / scale
+            assert err.max() <= 2e-11, (kw, name, err)
+        done += 1
