@@ -394,3 +394,33 @@ def test_ssf_matrix_core_kernel_vs_numpy(n, modes):
         np.abs(ssf[-1] - ref).max() / scale
     ens.close()
     eng.close()
+
+
+@pytest.mark.parametrize('n,bins', [(16, 256), (70, 200), (300, 33), (9, 5)])
+def test_density_kernel_vs_numpy(n, bins):
+    """Density histogram of the first estimator step against numpy on the
+    yielded walkers, for bin counts above the 64 lanes of a wavefront and
+    particle counts above one chunk."""
+    from math import pi
+    from phd_qmclib_amd import mrbp_qmc
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    spec = mrbp_qmc.Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                         interaction_strength=2, boson_number=n,
+                         supercell_size=n, tbf_contact_cutoff=0.25 * n)
+    eng = ModelEngine(spec.cfc_spec)
+    rng = np.random.RandomState(n * bins)
+    W = 200
+    ens = DmcEnsemble(eng, 1e-3, 256, W, 0.5, rng_seed=2)
+    ens.set_state(n * rng.random_sample((W, n)))
+    ens.set_estimators(num_bins=bins)
+    ser, _, dens = ens.run_block_est(1, True)
+    st = ens.get_state()
+    nw = st.num_walkers
+    z = st.confs[:nw, 0, :]
+    idx = np.clip(np.floor(z / (n / bins)).astype(int), 0, bins - 1)
+    ref = np.bincount(idx.ravel(), minlength=bins).astype(float)
+    assert dens.shape == (1, bins, 1)
+    assert np.array_equal(dens[0, :, 0], ref)
+    assert dens.sum() == nw * n
+    ens.close()
+    eng.close()
