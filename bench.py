@@ -2,36 +2,60 @@
 """bench.py -- walker-steps/s of the MI355X walker-propagation engine.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE
-JSON line on rank 0.  A "step" is one pass of the hot path over the whole
-ensemble: one all-particle Metropolis step (VMC) of every chain, including the
-local-energy evaluation.  The workload is BASELINE.json configs[1]: mrbp_qmc
-VMC, N = 64 bosons, 2^20 chains per GPU ("mrbp_qmc box").
-Chains are independent, so ranks shard them with no data-path collective
-(weak scaling: 2^20 chains on every GPU); only the final block sums are
-all-reduced.  `extra.dmc` reports the DMC configuration (configs[2], N = 64,
-2^18 target walkers) measured in the same run on rank 0's GPU.
+JSON line (rank 0).  With N > 1 and no RANK in the environment this process
+spawns the N ranks itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, before anything here touches the GPU runtime) and relays rank
+0's line; under `torch.distributed.run` it is one of the ranks.
 
-Inputs are resident in HBM when the timed region starts.  `roofline` is the
-HBM view the metric contract asks for (algorithmic bytes of SURVEY.md 8d over
-the measured kernel time); the path is fp64-VALU bound, so `extra.valu`
-gives the pair-evaluation rate as well.  `cpu_baseline` times the CPU oracle
-(C restatement of the reference algorithm, OpenMP over chains) on a bounded
-sample of the same workload, rank 0 only.
+What a "step" is and which workload is the headline:
+
+* N = 1 -- BASELINE.json configs[1]: mrbp_qmc VMC, N = 64 bosons, 2^20
+  independent chains; a step is one all-particle Metropolis step of every
+  chain including the local energy.  `extra.dmc` is configs[2] (DMC, N = 64,
+  2^18 walkers) and `extra.c4_dmc_sharded` the multi-GPU workload run on this
+  one GPU (the strong-scaling reference point).
+* N > 1 -- BASELINE.json configs[3]: mrbp_qmc DMC, N = 128 bosons, ONE
+  population of 2^22 walkers (global target) sharded over the ranks
+  (`dist.DistributedDmc`): per time step every rank branches and propagates
+  its walkers, a 16-byte RCCL all-reduce gives the global (E_t, W_t) for the
+  E_ref feedback, and the ranks level their populations with point-to-point
+  walker transfers.  Total work is fixed as N grows: `"scaling": "strong"`.
+  `extra.vmc_weak` is the VMC workload at 2^20 chains per GPU.
+
+The ensembles start from EQUILIBRATED configurations (>= 300 untimed
+Metropolis steps, which also lets the clock settle) and the result windows
+(energy per particle, acceptance) are asserted in here.  Inputs are resident in
+HBM when a timed region starts.  `roofline` is the HBM view the metric contract
+asks for: algorithmic bytes of SURVEY.md 8(d) over the dominant kernel's own
+duration, measured with HIP events on the stream it is launched on; the path
+is fp64-VALU bound, so `extra.valu` gives the pair-evaluation rate as well.
+`cpu_baseline` (N = 1, rank 0) times the CPU oracle -- the C restatement of
+the reference algorithm, OpenMP over chains, rebuilt here with -O3
+-march=native -- on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from math import pi
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_PEAK_TFLOPS = 78.6        # vector fp64, MI355X datasheet
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'traffic.json')
+
+# result windows of the equilibrated "mrbp_qmc box" (V0 = 5 E_R, r = 1, g = 2,
+# unit filling, rm = L / 4): E/N and acceptance of the trial state and the
+# DMC mixed estimate, N = 64 ... 128 (tests/test_gpu_sampling.py pins them
+# against the oracle; here they guard the benchmark against timing garbage)
+VMC_E_WINDOW = (15.30, 15.50)
+VMC_ACC_WINDOW = (0.46, 0.53)
+DMC_E_WINDOW = (15.25, 15.50)
 
 
 def box_spec(n):
@@ -41,64 +65,203 @@ def box_spec(n):
                 tbf_contact_cutoff=0.25 * n)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=64)
     ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--equil', type=int, default=320,
+                    help='untimed equilibration steps before --warmup')
     ap.add_argument('--block', type=int, default=16,
                     help='Metropolis steps enqueued per block call')
     ap.add_argument('--bosons', type=int, default=64)
     ap.add_argument('--chains', type=int, default=1 << 20,
                     help='VMC chains per GPU')
     ap.add_argument('--dmc-walkers', type=int, default=1 << 18)
+    ap.add_argument('--c4-bosons', type=int, default=128)
+    ap.add_argument('--c4-walkers', type=int, default=1 << 22,
+                    help='GLOBAL target population of the sharded DMC run')
+    ap.add_argument('--rebalance-every', type=int, default=16)
     ap.add_argument('--no-dmc', action='store_true')
+    ap.add_argument('--no-c4', action='store_true',
+                    help='skip the sharded-DMC workload at --gpus 1')
+    ap.add_argument('--no-vmc-extra', action='store_true',
+                    help='skip the weak-scaled VMC extra at --gpus > 1')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--dmc-dist', action='store_true',
-                    help='also time ONE DMC population sharded over all ranks '
-                         '(per-step RCCL all-reduce of (E_t, W_t) + rebalance)')
+    ap.add_argument('--no-checks', action='store_true',
+                    help='do not assert the energy / acceptance windows '
+                         '(other models or sizes than the benchmark box)')
+    ap.add_argument('--fp32', action='store_true',
+                    help='also time the reduced-precision (fp32 pair loop) '
+                         'variant as an extra line (never the headline)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------- launcher --
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """Spawn one child per GPU and relay rank 0's JSON line.  Nothing in this
+    process has touched the GPU runtime (no torch.cuda, no HIP call), and no
+    process is replaced: the children are ordinary subprocesses."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       'HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + list(argv),
+            env=env, stdout=subprocess.PIPE if r == 0 else None))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------- backend --
+class HipBackend:
+    """The product path: HIP engine + RCCL.  (The CPU tests of the launcher
+    substitute a stand-in through QMC_BENCH_BACKEND=<module>; nothing in this
+    file falls back to it.)"""
+    dist_backend = 'nccl'
+    has_vmc = True
+
+    def __init__(self, local_rank):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU (the HIP engine has no '
+                             'CPU path)')
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.local_rank = local_rank
+        self.device = torch.device('cuda', local_rank)
+        # one side stream for everything: the engine launches on it and RCCL
+        # orders its collectives with it (dist.DistributedDmc checks this)
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
+        self._engines = {}
+
+    def engine(self, n, fast_math=False):
+        from phd_qmclib_amd.engine import ModelEngine
+        key = (n, bool(fast_math))
+        if key not in self._engines:
+            kw = dict(fast_math=True) if fast_math else {}
+            self._engines[key] = ModelEngine(
+                box_spec(n).cfc_spec, device=self.local_rank,
+                stream=self.stream.cuda_stream, **kw)
+        return self._engines[key]
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def equilibrated_vmc(self, n, chains, chain0, equil, seed_rank,
+                         fast_math=False):
+        """A VMC ensemble of `chains` chains of the N = n box after `equil`
+        Metropolis steps from a uniform random start."""
+        import numpy as np
+        from phd_qmclib_amd.engine import VmcEnsemble
+        spec = box_spec(n)
+        eng = self.engine(n, fast_math)
+        rng = np.random.RandomState(1000 + seed_rank)
+        v = VmcEnsemble(eng, chains, 0.25 * spec.well_width, rng_seed=1,
+                        chain0=chain0)
+        # generated in slabs: 2^20 x 64 doubles is 512 MiB as it is
+        pos = np.empty((chains, n))
+        for lo in range(0, chains, 1 << 16):
+            hi = min(chains, lo + (1 << 16))
+            pos[lo:hi] = spec.supercell_size * rng.random_sample((hi - lo, n))
+        v.set_state(pos)
+        del pos
+        done = 0
+        while done < equil:
+            b = min(64, equil - done)
+            v.run_block(b, sums=False)
+            done += b
+        return v
+
+    def sharded_population(self, n, per_rank, cap, global_target, rank, world,
+                           equil, rebalance_every):
+        """This rank's share of ONE DMC population (external reduce) and its
+        DistributedDmc driver; the walkers start from equilibrated VMC
+        configurations, reused cyclically when there are fewer chains."""
+        import torch.distributed as dist
+        from phd_qmclib_amd.dist import DistributedDmc
+        from phd_qmclib_amd.engine import DmcEnsemble
+        torch = self.torch
+        eng = self.engine(n)
+        chains = min(per_rank, 1 << 17)
+        v = self.equilibrated_vmc(n, chains, rank * chains, equil, rank)
+        d = DmcEnsemble(eng, 6.25e-4, cap, global_target, 0.5, rng_seed=1,
+                        slot0=rank * cap, external_reduce=True)
+        d.set_state_from_vmc(v, per_rank, replicate=True)
+        # every rank must start from the same E_ref: the global mean energy
+        er = torch.tensor([d.get_scalars()[2]], dtype=torch.float64,
+                          device=self.device)
+        if world > 1:
+            dist.all_reduce(er)
+        d.set_state_from_vmc(v, per_rank, ref_energy=float(er.item()) / world,
+                             replicate=True)
+        v.close()
+        dd = DistributedDmc(d, n, self.device,
+                            rebalance_every=rebalance_every)
+        return d, dd, eng, chains
+
+
+def load_backend(local_rank):
+    name = os.environ.get('QMC_BENCH_BACKEND')
+    if name:                     # tests/ only: launcher + host logic on CPU
+        import importlib
+        return importlib.import_module(name).Backend(local_rank)
+    return HipBackend(local_rank)
+
+
+def check_window(what, value, window, args):
+    if args.no_checks:
+        return
+    lo, hi = window
+    if not (lo <= value <= hi):
+        raise SystemExit(f'bench.py: {what} = {value:.5f} outside the '
+                         f'expected window [{lo}, {hi}] -- refusing to '
+                         f'report a throughput for a wrong result')
+
+
+def load_traffic(n):
+    """Measured HBM bytes / VALU instructions per unit (rocprofv3 PMC passes
+    of tools/profile.sh, committed under profiles/)."""
+    try:
+        with open(TRAFFIC_JSON) as fp:
+            return json.load(fp).get(f'N{n}', {})
+    except (OSError, ValueError):
+        return {}
+
+
+# ---------------------------------------------------------------- VMC leg ---
+def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False):
+    """Timed VMC run of this rank's W chains -> dict of raw measurements."""
     import torch
     import torch.distributed as dist
-
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
-    torch.cuda.set_device(local_rank)
-    use_pg = world > 1 or 'RANK' in os.environ      # launched by torchrun
-    if use_pg:
-        dist.init_process_group('nccl', device_id=torch.device('cuda',
-                                                               local_rank))
-
-    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
-
-    n = args.bosons
-    W = args.chains
-    spec = box_spec(n)
-    cfc = spec.cfc_spec
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = ModelEngine(cfc, device=local_rank, stream=stream)
+    eng = be.engine(n, fast_math)
+    vmc = be.equilibrated_vmc(n, W, rank * W, args.equil, rank, fast_math)
 
     def barrier():
         if use_pg:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---------------- VMC, configs[1] ----------------
-    move_spread = 0.25 * spec.well_width
-    rng = np.random.RandomState(1000 + rank)
-    pos = spec.supercell_size * rng.random_sample((W, n))
-    vmc = VmcEnsemble(eng, W, move_spread, rng_seed=1, chain0=rank * W)
-    vmc.set_state(pos)
-    del pos
+        be.sync()
 
     def run_steps(k):
-        # one kernel launch per Metropolis step (the block call enqueues
-        # `b` launches without a host synchronisation)
         done = 0
         while done < k:
             b = min(args.block, k - done)
@@ -114,61 +277,49 @@ def main():
     kernel_ms = eng.timer_stop()          # HIP events on the launch stream
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
     if use_pg:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    # spread of the launch time (SURVEY.md 8d asks for median and min): a few
-    # more chunks, each bracketed by its own HIP events, outside the timed region
-    chunk_ms = []
-    for _ in range(6):
-        eng.timer_start()
-        vmc.run_block(args.block, sums=False)
-        chunk_ms.append(eng.timer_stop() / args.block)
-    chunk_ms.sort()
-
-    # block estimators of the last block (global reduction over ranks)
-    se_ptr, se2_ptr, na_ptr = vmc.block_sums_dev()
+        dt = float(tmax.item())
+    # per-launch spread: every launch bracketed by its own event pair
+    eng.profile_begin(args.block * 4)
+    vmc.run_block(args.block * 4, sums=False)
+    nl, tot_ms, min_ms, max_ms = eng.profile_end()
+    # block estimators of one more block (global reduction over ranks)
     res = vmc.run_block(args.block, sums=True)
-    tot = torch.tensor([res['sum_energy'].sum(), float(res['num_accepted'].sum()),
+    tot = torch.tensor([res['sum_energy'].sum(),
+                        float(res['num_accepted'].sum()),
                         float(W * args.block)], dtype=torch.float64,
-                       device='cuda')
+                       device=be.device)
     if use_pg:
         dist.all_reduce(tot)
     tot = tot.cpu().numpy()
+    return dict(vmc=vmc, eng=eng, dt=dt, kernel_ms=kernel_ms,
+                launches=launches,
+                launch_ms_avg_isolated=tot_ms / max(nl, 1),
+                launch_ms_min=min_ms, launch_ms_max=max_ms,
+                energy_per_particle=float(tot[0] / tot[2] / n),
+                accept_rate=float(tot[1] / tot[2]))
 
-    value = world * W * args.steps / dt
+
+def vmc_line(args, m, n, W, world):
+    """The headline JSON object of the VMC workload from measurements `m`."""
+    value = world * W * args.steps / m['dt']
     b_vmc = 16 * n + 32                      # SURVEY.md 8(d), bytes/chain-step
-    launch_ms = kernel_ms / launches
-    steps_per_launch = args.steps / launches
-    achieved = W * steps_per_launch * b_vmc / (launch_ms * 1e-3) / 1e9
+    launch_ms = m['kernel_ms'] / m['launches']
+    achieved = W * b_vmc / (launch_ms * 1e-3) / 1e9
     pairs = n * (n - 1) // 2
-    pair_rate = W * args.steps * pairs / (kernel_ms * 1e-3)
-
-    # measured HBM traffic per chain-step (rocprofv3 FETCH_SIZE/WRITE_SIZE passes,
-    # profiles/r01_traffic.json), scaled to the units of one launch
-    traffic = None
-    valu_per_step = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as fp:
-            tj = json.load(fp)
-        if n == 64:
-            traffic = tj['vmc_step_kernel_bytes_per_chain_step_N64'] * W * \
-                steps_per_launch
-            valu_per_step = tj.get(
-                'vmc_step_kernel_valu_instr_per_chain_step_N64')
-    except (OSError, KeyError, ValueError):
-        pass
-
-    out = {
+    tj = load_traffic(n)
+    traffic = tj.get('vmc_step_kernel_bytes_per_chain_step')
+    valu = tj.get('vmc_step_kernel_valu_instr_per_chain_step')
+    return {
         'metric': 'walker-steps/sec',
         'value': value,
         'unit': 'walker-steps/s',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': dt / args.steps * 1e3,
+        'ms_per_step': m['dt'] / args.steps * 1e3,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -176,145 +327,338 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': f'mrbp_qmc VMC, N={n} bosons, {W} chains per GPU, '
-                        f'move_spread=0.25*well_width, energy on accepted moves',
+                        f'move_spread=0.25*well_width, energy on accepted '
+                        f'moves, equilibrated start ({args.equil} steps)',
             'bosons': n, 'chains_per_gpu': W, 'steps_per_launch': 1,
-            'parallelism': f'chains sharded over {world} GPU(s), no data-path '
-                           f'collective',
+            'parallelism': f'chains sharded over {world} GPU(s), no '
+                           f'data-path collective',
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None if traffic is None else traffic * W,
             'kernel': 'vmc_step_kernel', 'launch_ms': launch_ms,
-            'bytes_per_unit': b_vmc,
+            'bytes_per_unit': b_vmc, 'units_per_launch': W,
         },
         'extra': {
-            'valu': {'pair_evals_per_s': pair_rate,
-                     # the ceiling that binds: wave64 VALU instructions issued
-                     # (SQ_INSTS_VALU / SQ_WAVES of the rocprofv3 PMC pass,
-                     # profiles/r01_traffic.json) against 1 instruction per 4
-                     # cycles per SIMD, 4 SIMDs x 256 CUs at 2.4 GHz
-                     'instr_per_chain_step': valu_per_step,
-                     'issue_frac': None if valu_per_step is None else
-                     (W * steps_per_launch * valu_per_step /
-                      (launch_ms * 1e-3)) / (1024 * 2.4e9 / 4),
-                     'note': 'the path is fp64-VALU bound (SURVEY.md 8d); '
-                             'unique pairs N(N-1)/2 per chain-step'},
-            'launch_ms_min': chunk_ms[0],
-            'launch_ms_median': 0.5 * (chunk_ms[2] + chunk_ms[3]),
-            'vmc_energy_per_particle': float(tot[0] / tot[2] / n),
-            'vmc_accept_rate': float(tot[1] / tot[2]),
+            'valu': {
+                'pair_evals_per_s': W * args.steps * pairs /
+                (m['kernel_ms'] * 1e-3),
+                # the ceiling that binds: wave64 VALU instructions issued
+                # (SQ_INSTS_VALU / SQ_WAVES of the rocprofv3 PMC pass) against
+                # 1 instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz
+                'instr_per_chain_step': valu,
+                'issue_frac': None if valu is None else
+                (W * valu / (launch_ms * 1e-3)) / (1024 * 2.4e9 / 4),
+                'note': 'the path is fp64-VALU bound (SURVEY.md 8d); unique '
+                        'pairs N(N-1)/2 per chain-step'},
+            'launch_ms_isolated_avg': m['launch_ms_avg_isolated'],
+            'launch_ms_min': m['launch_ms_min'],
+            'launch_ms_max': m['launch_ms_max'],
+            'vmc_energy_per_particle': m['energy_per_particle'],
+            'vmc_accept_rate': m['accept_rate'],
         },
     }
 
-    # ---------------- DMC, configs[2] (rank 0's GPU, informational) -------
-    if not args.no_dmc and rank == 0:
-        target = args.dmc_walkers
-        maxw = ((target * 512 // 480) + 255) // 256 * 256
-        pos0, _, _ = vmc.get_state()
-        d = DmcEnsemble(eng, 6.25e-4, maxw, target, 0.5, rng_seed=1)
-        d.set_state(pos0[:target])
-        del pos0
-        d.run_block(args.warmup, read=False)
-        eng.sync()
-        eng.timer_start()
-        t0 = time.perf_counter()
-        d.run_block(args.steps, read=False)
-        dmc_ms = eng.timer_stop()
-        ddt = time.perf_counter() - t0
-        ser = d.read_series(args.steps)
-        nws = float(ser.num_walkers.sum())
-        b_dmc = 32 * n + 40 + 16
-        out['extra']['dmc'] = {
-            'workload': f'mrbp_qmc DMC, N={n}, target {target} / max {maxw} '
-                        f'walkers, dt=6.25e-4',
-            'walker_steps_per_s': nws / ddt,
-            'ms_per_step': ddt / args.steps * 1e3,
-            'hbm_achieved_GBs': nws * b_dmc / (dmc_ms * 1e-3) / 1e9,
-            'hbm_frac': nws * b_dmc / (dmc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            'mean_walkers': nws / args.steps,
-            'energy_per_particle': float(ser.energy.sum() / ser.weight.sum() / n),
-        }
-        d.close()
 
-    # ---------------- DMC, one population over all ranks (opt-in) ---------
-    if args.dmc_dist:
-        from phd_qmclib_amd.dist import DistributedDmc
-        per_rank = args.dmc_walkers
-        target = per_rank * world
-        cap = ((per_rank * 512 // 480) + 255) // 256 * 256
-        pos0, _, _ = vmc.get_state()
-        d = DmcEnsemble(eng, 6.25e-4, cap, target, 0.5, rng_seed=1,
-                        slot0=rank * cap, external_reduce=True)
-        d.set_state(pos0[:per_rank])
-        # every rank must start from the same E_ref: the global mean energy
-        er = torch.tensor([d.get_state().ref_energy], dtype=torch.float64,
-                          device='cuda')
+# ---------------------------------------------------------------- DMC legs --
+def bench_dmc_single(be, args, n, vmc, target):
+    """configs[2]: one DMC population on this GPU, started device to device
+    from the equilibrated VMC chains."""
+    from phd_qmclib_amd.engine import DmcEnsemble
+    eng = be.engine(n)
+    maxw = ((target * 512 // 480) + 255) // 256 * 256
+    d = DmcEnsemble(eng, 6.25e-4, maxw, target, 0.5, rng_seed=1)
+    d.set_state_from_vmc(vmc, target, replicate=True)
+    d.run_block(max(args.warmup, 8), read=False)
+    eng.sync()
+    eng.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    d.run_block(args.steps, read=False)
+    nl, evolve_ms, _, _ = eng.profile_end()       # synchronises
+    ddt = time.perf_counter() - t0
+    ser = d.read_series(args.steps)
+    nws = float(ser.num_walkers.sum())
+    b_dmc = 32 * n + 40 + 16
+    e_per = float(ser.energy.sum() / ser.weight.sum() / n)
+    d.close()
+    check_window('DMC energy per particle', e_per, DMC_E_WINDOW, args)
+    return {
+        'workload': f'mrbp_qmc DMC, N={n}, target {target} / max {maxw} '
+                    f'walkers, dt=6.25e-4, from equilibrated VMC chains',
+        'walker_steps_per_s': nws / ddt,
+        'ms_per_step': ddt / args.steps * 1e3,
+        'evolve_kernel_ms': evolve_ms / max(nl, 1),
+        'hbm_achieved_GBs': nws * b_dmc / (evolve_ms * 1e-3) / 1e9,
+        'hbm_frac': nws * b_dmc / (evolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        'mean_walkers': nws / args.steps,
+        'energy_per_particle': e_per,
+    }
+
+
+def bench_dmc_sharded(be, args, rank, world, use_pg):
+    """configs[3]: ONE population of --c4-walkers (global target) sharded over
+    the ranks.  -> dict (identical on every rank)."""
+    import torch
+    import torch.distributed as dist
+    n = args.c4_bosons
+    target = args.c4_walkers
+    per_rank = target // world
+    cap = ((per_rank * 512 // 480) + 255) // 256 * 256
+    d, dd, eng, chains = be.sharded_population(
+        n, per_rank, cap, target, rank, world, args.equil,
+        args.rebalance_every)
+
+    def barrier():
         if use_pg:
-            dist.all_reduce(er)
-        d.set_state(pos0[:per_rank], ref_energy=float(er.item()) / world)
-        del pos0
-        dd = DistributedDmc(d, n, torch.device('cuda', local_rank),
-                            rebalance_every=32)
-        dd.run_block(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        ser = dd.run_block(args.steps)
-        barrier()
-        ddt = time.perf_counter() - t0
-        loc = torch.tensor([float(ser.num_walkers.sum()), ddt],
-                           dtype=torch.float64, device='cuda')
-        tmx = loc[1:].clone()
-        if use_pg:
-            dist.all_reduce(loc[:1])
-            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
-        if rank == 0:
-            out['extra']['dmc_dist'] = {
-                'workload': f'mrbp_qmc DMC, N={n}, ONE population of target '
-                            f'{target} walkers sharded over {world} rank(s), '
-                            f'16-byte all-reduce per step, rebalance every 32',
-                'walker_steps_per_s': float(loc[0].item()) / float(tmx.item()),
-                'ms_per_step': float(tmx.item()) / args.steps * 1e3,
-                'walkers_moved_rank0': dd.walkers_moved,
-                'energy_per_particle':
-                    float(ser.energy.sum() / ser.weight.sum() / n),
+            dist.barrier()
+        be.sync()
+
+    dd.run_block(max(args.warmup, 1))
+    barrier()
+    if eng is not None:
+        eng.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    ser = dd.run_block(args.steps)
+    barrier()
+    ddt = time.perf_counter() - t0
+    nl, evolve_ms = 0, 0.0
+    if eng is not None:
+        nl, evolve_ms, _, _ = eng.profile_end()
+    import numpy as np
+    nw_local = float(np.sum(_series_field(ser, 'num_walkers', 2)))
+    e_glob = _series_field(ser, 'energy', 0)
+    w_glob = _series_field(ser, 'weight', 1)
+    loc = torch.tensor([nw_local, ddt, evolve_ms, float(dd.walkers_moved),
+                        float(dd.rebalances)],
+                       dtype=torch.float64, device=be.device)
+    tmx = loc.clone()
+    if use_pg:
+        dist.all_reduce(loc)                         # sums
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)   # maxima
+    nws = float(loc[0].item())
+    tmax = float(tmx[1].item())
+    evolve_max = float(tmx[2].item())
+    e_per = float(np.sum(e_glob) / np.sum(w_glob) / n)
+    check_window('sharded DMC energy per particle', e_per, DMC_E_WINDOW, args)
+    b_dmc = 32 * n + 40 + 16
+    out = {
+        'workload': f'mrbp_qmc DMC, N={n} bosons, ONE population of target '
+                    f'{target} walkers sharded over {world} rank(s) '
+                    f'({per_rank} per rank, cap {cap}), dt=6.25e-4, 16-byte '
+                    f'all-reduce of (E_t, W_t) per step, rebalance check '
+                    f'every {args.rebalance_every} steps; walkers start '
+                    f'from {chains} equilibrated VMC chains per rank',
+        'walker_steps_per_s': nws / tmax,
+        'ms_per_step': tmax / args.steps * 1e3,
+        'walker_steps': nws,
+        'bosons': n, 'global_target': target, 'per_rank': per_rank,
+        'mean_walkers': nws / args.steps,
+        'energy_per_particle': e_per,
+        'walkers_moved_all_ranks': float(loc[3].item()),
+        'rebalances_max': float(tmx[4].item()),
+        'bytes_per_unit': b_dmc,
+    }
+    if nl:
+        # the slowest rank's evolve kernel: walkers per launch on that rank ~
+        # nws / world / steps
+        launch_ms = evolve_max / nl
+        units = nws / world / args.steps
+        out.update(evolve_kernel_ms=launch_ms,
+                   hbm_achieved_GBs=units * b_dmc / (launch_ms * 1e-3) / 1e9,
+                   units_per_launch=units)
+    if hasattr(d, 'close'):
+        d.close()
+    return out
+
+
+def _series_field(ser, name, col):
+    if hasattr(ser, name):
+        return getattr(ser, name)
+    return ser[:, col]
+
+
+def sharded_line(args, s, world):
+    """Headline JSON object of the sharded DMC workload."""
+    n = args.c4_bosons
+    achieved = s.get('hbm_achieved_GBs')
+    tj = load_traffic(n)
+    traffic = tj.get('dmc_evolve_kernel_bytes_per_walker_step')
+    return {
+        'metric': 'walker-steps/sec',
+        'value': s['walker_steps_per_s'],
+        'unit': 'walker-steps/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': s['ms_per_step'],
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {
+            'workload': s['workload'],
+            'bosons': n, 'global_target_walkers': s['global_target'],
+            'walkers_per_gpu': s['per_rank'],
+            'parallelism': f'walkers sharded over {world} GPU(s); per step '
+                           f'one 16-byte RCCL all-reduce; p2p population '
+                           f'rebalance',
+        },
+        'roofline': {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': None if achieved is None else achieved / HBM_PEAK_GBS,
+            'traffic': None if traffic is None or 'units_per_launch' not in s
+            else traffic * s['units_per_launch'],
+            'kernel': 'dmc_evolve_kernel',
+            'launch_ms': s.get('evolve_kernel_ms'),
+            'bytes_per_unit': s['bytes_per_unit'],
+            'units_per_launch': s.get('units_per_launch'),
+        },
+        'extra': {
+            'dmc_energy_per_particle': s['energy_per_particle'],
+            'mean_walkers': s['mean_walkers'],
+            'walkers_moved_all_ranks': s['walkers_moved_all_ranks'],
+            'rebalances_max': s['rebalances_max'],
+        },
+    }
+
+
+# ------------------------------------------------------------ CPU baseline --
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(args, spec, n, move_spread):
+    """The oracle (C restatement of the reference algorithm) timed on this
+    box's host cores on a bounded sample of the VMC workload.  Built here with
+    -O3 -march=native (the committed checker build is -O2, bit-exact)."""
+    import numpy as np
+    from oracle import qmc_oracle as orc
+    flags = orc.build_native()          # -> flag string of the timed build
+    m = orc.model_from_cfc(spec.cfc_spec)
+    # the one-GPU box shares its host: use its CPU allotment, not every
+    # hardware thread the kernel reports
+    cores = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0)), 16))
+    rng = np.random.RandomState(7)
+    wc, ns = 64 * cores, 4
+    cpos = spec.supercell_size * rng.random_sample((wc, n))
+    cwf = np.array([orc.wf_abs_log(m, cpos[i]) for i in range(wc)])
+    cec = np.zeros(wc)
+    t0 = time.perf_counter()
+    orc.vmc_ensemble(m, cpos, cwf, cec, move_spread, 1, ns,
+                     yield_initial=True, nthreads=cores)
+    probe = time.perf_counter() - t0
+    # scale the sample to about cpu_seconds of work
+    ns2 = max(4, int(ns * args.cpu_seconds / max(probe, 1e-3)))
+    t0 = time.perf_counter()
+    orc.vmc_ensemble(m, cpos, cwf, cec, move_spread, 1, ns2, step0=ns,
+                     nthreads=cores)
+    cdt = time.perf_counter() - t0
+    return {
+        'value': wc * ns2 / cdt, 'unit': 'walker-steps/s', 'cores': cores,
+        'kind': 'port',
+        'sample': f'{wc} chains x {ns2} steps of the same VMC workload '
+                  f'(N={n}), oracle/qmc_oracle.c with OpenMP over chains',
+        'cpu_model': cpu_model(),
+        'compiler_flags': flags,
+        'hardware_threads': os.cpu_count(),
+    }
+
+
+# ------------------------------------------------------------------- main ---
+def run_rank(args):
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE is '
+                         f'{world}: launch {args.gpus} ranks (or run '
+                         f'`python bench.py --gpus {args.gpus}` and let it '
+                         f'spawn them)')
+    import torch.distributed as dist
+    be = load_backend(local_rank)
+    use_pg = world > 1 or 'RANK' in os.environ
+    if use_pg:
+        kw = {}
+        if be.dist_backend == 'nccl':
+            kw['device_id'] = be.device
+        dist.init_process_group(be.dist_backend, **kw)
+        world = dist.get_world_size()      # what the process group reports
+        rank = dist.get_rank()
+
+    n, W = args.bosons, args.chains
+    out = None
+    if world == 1:
+        # ---- headline: VMC, configs[1] ----
+        m = bench_vmc(be, args, rank, world, use_pg, n, W)
+        check_window('VMC energy per particle', m['energy_per_particle'],
+                     VMC_E_WINDOW, args)
+        check_window('VMC acceptance', m['accept_rate'], VMC_ACC_WINDOW, args)
+        out = vmc_line(args, m, n, W, world)
+        if not args.no_dmc:
+            out['extra']['dmc'] = bench_dmc_single(be, args, n, m['vmc'],
+                                                   args.dmc_walkers)
+        m['vmc'].close()
+        if args.fp32:
+            mf = bench_vmc(be, args, rank, world, use_pg, n, W,
+                           fast_math=True)
+            lf = vmc_line(args, mf, n, W, world)
+            out['extra']['vmc_fp32_pair_loop'] = {
+                'dtype': 'f32 pair loop (tables, sums, one-body, Metropolis '
+                         'in f64)',
+                'value': lf['value'], 'ms_per_step': lf['ms_per_step'],
+                'energy_per_particle': mf['energy_per_particle'],
+                'accept_rate': mf['accept_rate'],
+                'note': 'jit_fastmath analogue of the reference '
+                        '(mrbp_qmc/dmc.py:159-160); NOT the headline',
             }
-        d.close()
-
-    # ---------------- CPU baseline (oracle, rank 0, N = 1 only) -----------
-    if not args.no_cpu and rank == 0 and world == 1:
-        from oracle import qmc_oracle as orc
-        m = orc.model_from_cfc(cfc)
-        # the one-GPU box shares its host: use its CPU allotment, not every
-        # hardware thread the kernel reports
-        cores = max(1, min(orc.max_threads(), len(os.sched_getaffinity(0)), 16))
-        rng = np.random.RandomState(7)
-        wc, ns = 64 * cores, 4
-        cpos = spec.supercell_size * rng.random_sample((wc, n))
-        cwf = np.array([orc.wf_abs_log(m, cpos[i]) for i in range(wc)])
-        cec = np.zeros(wc)
-        t0 = time.perf_counter()
-        orc.vmc_ensemble(m, cpos, cwf, cec, move_spread, 1, ns,
-                         yield_initial=True, nthreads=cores)
-        probe = time.perf_counter() - t0
-        # scale the sample to about cpu_seconds of work
-        ns2 = max(4, int(ns * args.cpu_seconds / max(probe, 1e-3)))
-        t0 = time.perf_counter()
-        orc.vmc_ensemble(m, cpos, cwf, cec, move_spread, 1, ns2, step0=ns,
-                         nthreads=cores)
-        cdt = time.perf_counter() - t0
-        out['cpu_baseline'] = {
-            'value': wc * ns2 / cdt, 'unit': 'walker-steps/s', 'cores': cores,
-            'kind': 'port',
-            'sample': f'{wc} chains x {ns2} steps of the same VMC workload '
-                      f'(N={n}), oracle/qmc_oracle.c with OpenMP over chains',
-        }
-
+            mf['vmc'].close()
+        if not args.no_c4:
+            s = bench_dmc_sharded(be, args, rank, world, use_pg)
+            out['extra']['c4_dmc_sharded'] = dict(
+                s, note='the --gpus N > 1 headline workload on ONE GPU: the '
+                        'strong-scaling reference point')
+        if not args.no_cpu and rank == 0:
+            spec = box_spec(n)
+            out['cpu_baseline'] = cpu_baseline(args, spec, n,
+                                               0.25 * spec.well_width)
+    else:
+        # ---- headline: ONE sharded DMC population, configs[3] ----
+        s = bench_dmc_sharded(be, args, rank, world, use_pg)
+        out = sharded_line(args, s, world)
+        if be.has_vmc and not args.no_vmc_extra:
+            m = bench_vmc(be, args, rank, world, use_pg, n, W)
+            lv = vmc_line(args, m, n, W, world)
+            out['extra']['vmc_weak'] = {
+                'workload': lv['config']['workload'],
+                'value': lv['value'], 'ms_per_step': lv['ms_per_step'],
+                'scaling': 'weak',
+                'energy_per_particle': m['energy_per_particle'],
+                'accept_rate': m['accept_rate'],
+            }
+            m['vmc'].close()
     if rank == 0:
-        print(json.dumps(out))
-    vmc.close()
-    eng.close()
+        print(json.dumps(out), flush=True)
     if use_pg:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == '__main__':

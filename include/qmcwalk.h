@@ -15,8 +15,12 @@
  *   - "host" pointers are caller-owned CPU buffers; "dev" pointers are device
  *     (HBM) addresses.  All device memory of an ensemble is owned by its handle.
  *   - a handle is bound to one HIP device and one stream and is not
- *     thread-safe.  `stream` is a hipStream_t passed as void* (NULL = the
- *     engine creates its own non-blocking stream).
+ *     thread-safe.  `stream` is a hipStream_t passed as void*.
+ *     qmc_engine_create: NULL = the engine creates its own non-blocking
+ *     stream; qmc_engine_create_on_stream: the caller's stream as it is, NULL
+ *     being the legacy default stream (what torch.cuda.current_stream() is
+ *     unless a side stream is current) -- use it whenever another library
+ *     (torch.distributed / RCCL) must be stream-ordered with the engine.
  *   - configurations use the reference's row layout: positions pos[W][N],
  *     full system configurations confs[W][2][N] (row 0 position, row 1 drift;
  *     qmc_base/jastrow/model.py:31-38).
@@ -106,11 +110,24 @@ int qmc_device_count(int *count);
 /* ---- engine: model constants on one device --------------------------- */
 int qmc_engine_create(const qmc_model_params *model, int device, void *stream,
                       qmc_engine **out);
+int qmc_engine_create_on_stream(const qmc_model_params *model, int device,
+                                void *stream, qmc_engine **out);
 void qmc_engine_destroy(qmc_engine *eng);
+/* the stream the engine launches on; *owned = 1 if the engine created it */
+int qmc_engine_stream(qmc_engine *eng, void **stream, int *owned);
 int qmc_engine_sync(qmc_engine *eng);
 /* HIP-event timing on the engine's stream (bench / roofline) */
 int qmc_engine_timer_start(qmc_engine *eng);
 int qmc_engine_timer_stop(qmc_engine *eng, float *elapsed_ms);
+/* Kernel profile: while open, every launch of the dominant kernel of a step
+ * (vmc_step_kernel / dmc_evolve_kernel) is bracketed by its own HIP event
+ * pair on the engine's stream (at most max_launches of them); profile_end
+ * synchronises and returns the number of launches, the sum, the shortest and
+ * the longest of their durations.  bench.py derives roofline.achieved from
+ * it. */
+int qmc_engine_profile_begin(qmc_engine *eng, int64_t max_launches);
+int qmc_engine_profile_end(qmc_engine *eng, int64_t *launches,
+                           double *total_ms, double *min_ms, double *max_ms);
 
 /* Stands in for model.core_funcs.{wf_abs_log, energy, drift,
  * ith_energy_and_drift} (qmc_base/jastrow/model.py:298-366, 476-564, 756-773,
@@ -187,7 +204,8 @@ int qmc_dmc_set_state(qmc_dmc *d, int64_t nw, const double *pos,
                       int use_ref_energy, double ref_energy);
 /* build_state from positions already in HBM; set_state_from_vmc takes the
  * first nw chains of a VMC ensemble of the same engine (VMC -> DMC hand-off
- * without a host round trip, tests/mrbp_qmc/test_dmc.py:76-83). */
+ * without a host round trip, tests/mrbp_qmc/test_dmc.py:76-83); when nw
+ * exceeds the number of chains they are reused cyclically. */
 int qmc_dmc_set_state_dev(qmc_dmc *d, int64_t nw, const double *pos_dev,
                           int use_ref_energy, double ref_energy);
 int qmc_dmc_set_state_from_vmc(qmc_dmc *d, qmc_vmc *v, int64_t nw,
@@ -215,6 +233,15 @@ int qmc_dmc_run_block_est(qmc_dmc *d, int64_t nsteps, int eval_estimators,
                           double *energy, double *weight, uint64_t *num_walkers,
                           double *ref_energy, double *accum_energy,
                           double *iter_ssf, double *iter_density);
+/* The same for split-step (multi-GPU) drivers: est_begin_block opens a block
+ * of nsteps steps (per-block resets), step_estimators evaluates the
+ * estimators on the population yielded by the last step_finish into row
+ * step_idx of this rank's iter buffers, est_iter_dev returns their device
+ * addresses (iter_ssf[nsteps][num_modes][3], iter_density[nsteps][num_bins];
+ * sums over this rank's walkers: linear, so ranks add them up). */
+int qmc_dmc_est_begin_block(qmc_dmc *d, int64_t nsteps);
+int qmc_dmc_step_estimators(qmc_dmc *d, int64_t step_idx);
+int qmc_dmc_est_iter_dev(qmc_dmc *d, double **iter_ssf, double **iter_density);
 /* The yielded ("actual") State after the last step (qmc_base/dmc.py:773-780):
  * confs[maxw][2][N], energy/weight[maxw], mask[maxw], cloning_ref[maxw];
  * scalars[5] = energy, weight, ref_energy, accum_energy, num_walkers. */
@@ -231,12 +258,23 @@ int qmc_dmc_step_finish(qmc_dmc *d, const double *total_dev);
 int qmc_dmc_read_series(qmc_dmc *d, int64_t nsteps, double *energy,
                         double *weight, uint64_t *num_walkers,
                         double *ref_energy, double *accum_energy);
-/* Population rebalance: pack walkers [first, first+count) of the current
- * population into buf_dev[count][3N+2] (pos, drift, labels, energy, weight) / append
- * `count` packed walkers; truncate drops the tail. */
+/* Population rebalance.  A walker record is walker_record_size doubles: pos[N],
+ * drift[N], lane labels[N], energy, weight and, when estimators are set, the
+ * walker's forward-walking rows (S(k) parts [num_modes][3], density
+ * [num_bins]).  export packs walkers [first, first+count) of the current
+ * population into buf_dev; import_walkers_at writes `count` records into
+ * slots [first, first+count) and makes first+count the population size;
+ * set_num_walkers drops the tail.  These three are stream-ordered (no host
+ * synchronisation: the caller planned the transfer from num_walkers of every
+ * rank).  num_walkers, import_walkers (append at the device's count) and
+ * truncate (checked against it) read the device and synchronise. */
 int qmc_dmc_num_walkers(qmc_dmc *d, int64_t *nw);
+int qmc_dmc_walker_record_size(qmc_dmc *d, int64_t *doubles);
 int qmc_dmc_export_walkers(qmc_dmc *d, int64_t first, int64_t count,
                            double *buf_dev);
+int qmc_dmc_import_walkers_at(qmc_dmc *d, int64_t first, int64_t count,
+                              const double *buf_dev);
+int qmc_dmc_set_num_walkers(qmc_dmc *d, int64_t nw);
 int qmc_dmc_import_walkers(qmc_dmc *d, int64_t count, const double *buf_dev);
 int qmc_dmc_truncate(qmc_dmc *d, int64_t new_nw);
 /* TEST ONLY: replay recorded streams.  u[] / g[] are host arrays; step t

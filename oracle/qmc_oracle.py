@@ -77,13 +77,46 @@ def build(force=False):
 
 
 _lib = None
+_active_path = _LIB_PATH
+NATIVE_FLAGS = ('-O3 -march=native -fPIC -fopenmp -ffp-contract=off '
+                '-fno-builtin -std=gnu11')
+
+
+def build_native():
+    """For the `cpu_baseline` leg of bench.py: rebuild the oracle ON THE BOX
+    THAT RUNS IT with -O3 -march=native (the committed Makefile
+    builds the bit-exact checker with -O2 and no target flags, and a
+    -march=native object must not travel between machines) and make it the
+    library `lib()` loads from now on.  Still no -ffast-math and no FMA
+    contraction: the reference default is jit_fastmath=False.
+    -> the flag string of the build in use."""
+    global _lib, _active_path
+    import tempfile
+    out_dir = os.path.join(tempfile.gettempdir(),
+                           f'qmc_oracle_native_{os.getuid()}')
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, 'libqmc_oracle_native.so')
+    cc = os.environ.get('CC', 'gcc')
+    cmd = [cc] + NATIVE_FLAGS.split() + ['-shared', '-o', out,
+                                         os.path.join(_HERE, 'qmc_oracle.c'),
+                                         '-lm']
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        build()
+        return 'gcc -O2 (oracle/Makefile; native rebuild failed)'
+    _active_path = out
+    _lib = None
+    return f'{cc} {NATIVE_FLAGS}'
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        if _active_path == _LIB_PATH:
+            build()
+        L = C.CDLL(_active_path)
         L.orc_wf_abs_log.restype = C.c_double
         L.orc_wf_abs_log.argtypes = [C.POINTER(OrcModel), _dp]
         L.orc_energy_drift.restype = C.c_double

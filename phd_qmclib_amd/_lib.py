@@ -67,7 +67,12 @@ SIGNATURES = {
     'qmc_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'qmc_engine_create': (C.c_int, [C.POINTER(ModelParams), C.c_int, _vp,
                                     C.POINTER(_vp)]),
+    'qmc_engine_create_on_stream': (C.c_int, [C.POINTER(ModelParams), C.c_int,
+                                              _vp, C.POINTER(_vp)]),
     'qmc_engine_destroy': (None, [_vp]),
+    'qmc_engine_stream': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
+    'qmc_engine_profile_begin': (C.c_int, [_vp, C.c_int64]),
+    'qmc_engine_profile_end': (C.c_int, [_vp, _i64p, _dp, _dp, _dp]),
     'qmc_engine_sync': (C.c_int, [_vp]),
     'qmc_engine_timer_start': (C.c_int, [_vp]),
     'qmc_engine_timer_stop': (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -102,6 +107,9 @@ SIGNATURES = {
     'qmc_dmc_set_estimators': (C.c_int, [_vp, C.POINTER(DmcEstParams)]),
     'qmc_dmc_run_block_est': (C.c_int, [_vp, C.c_int64, C.c_int, _dp, _dp,
                                         _u64p, _dp, _dp, _dp, _dp]),
+    'qmc_dmc_est_begin_block': (C.c_int, [_vp, C.c_int64]),
+    'qmc_dmc_step_estimators': (C.c_int, [_vp, C.c_int64]),
+    'qmc_dmc_est_iter_dev': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     'qmc_dmc_get_state': (C.c_int, [_vp, _dp, _dp, _dp, _u8p, _i64p, _dp]),
     'qmc_dmc_step_local': (C.c_int, [_vp, _vp]),
     'qmc_dmc_step_finish': (C.c_int, [_vp, _vp]),
@@ -110,6 +118,9 @@ SIGNATURES = {
     'qmc_dmc_num_walkers': (C.c_int, [_vp, _i64p]),
     'qmc_dmc_export_walkers': (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
     'qmc_dmc_import_walkers': (C.c_int, [_vp, C.c_int64, _vp]),
+    'qmc_dmc_walker_record_size': (C.c_int, [_vp, _i64p]),
+    'qmc_dmc_import_walkers_at': (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
+    'qmc_dmc_set_num_walkers': (C.c_int, [_vp, C.c_int64]),
     'qmc_dmc_truncate': (C.c_int, [_vp, C.c_int64]),
     'qmc_dmc_set_tape': (C.c_int, [_vp, _dp, C.c_int64, _dp, C.c_int64, _i64p,
                                    _i64p, C.c_int64]),

@@ -35,6 +35,14 @@
 
 #define QMC_PI 3.141592653589793238462643383279502884
 
+// Section markers for the static instruction census (tools/isa_one.sh builds
+// with -DQMC_SECTIONS; the production build emits nothing).
+#ifdef QMC_SECTIONS
+#define QMC_SECTION(name) asm volatile("; SECTION " name)
+#else
+#define QMC_SECTION(name) do { } while (0)
+#endif
+
 struct DevModel {
     int n;                 // boson_number
     int is_free, is_ideal;
@@ -455,6 +463,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     double Kown[P], KT[P];   // per-particle pair kinetic sums (ITH)
     double T[P];             // travelling drift of the partner lane
 
+    QMC_SECTION("tables+onebody");
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         ok[a] = !PAD || (gl + G * a) < n;
@@ -541,6 +550,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     ((isshort) ? fma(q, q, m.k2sq) : fma((q) * (q), m.inv_beta, m.b_long))
 
         // ---- k = 0: pairs inside the lane ----
+        QMC_SECTION("pairs_in_lane");
 #pragma unroll
         for (int a = 0; a < P; ++a) {
             PTab ta; double aksa, akca;
@@ -655,8 +665,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             }                                                                 \
             /* (kept rolled: unrolled, the scheduler hoists the LDS reads of \
                every copy and the kernel loses half its occupancy: -8 %) */  \
+            QMC_SECTION("rotation_loop_body");                                \
             for (int k = 1; k < G / 2; ++k)                                   \
                 QMC_KSTEP(H, k, false)                                        \
+            QMC_SECTION("rotation_last_step");                                \
             QMC_KSTEP(H, G / 2, true)                                         \
             /* deliver the travelling sums to their owners (lane gl ^ G/2    \
                holds them) and start the next pass from zero */              \
@@ -677,6 +689,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     }
 
     // ---- local energy ----
+    QMC_SECTION("energy+logwf");
     double e_lane = 0.0;
     if (ITH) {
 #pragma unroll

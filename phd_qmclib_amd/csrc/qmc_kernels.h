@@ -1,0 +1,378 @@
+// qmc_kernels.h -- the __global__ kernels of libqmcwalk.so and their argument
+// blocks (host API and launch code: qmcwalk.hip; device building blocks:
+// qmc_device.h).  Kept in a header so that a single instantiation can be
+// compiled on its own (tools/isa_one.sh: ISA dumps, instruction counts).
+#pragma once
+
+#include "qmc_device.h"
+
+static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
+
+// --------------------------------------------------------------- kernels ---
+struct EvalArgs {
+    const double *pos;   // [W][N]
+    double *wf, *energy; // [W]
+    double *ith, *drift; // [W][N]
+    long long nconf;
+};
+
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
+{
+    // model constants live in device memory: scalar loads on demand keep the
+    // SGPR file free for the hot loop (by-value they overflow it)
+    const DevModel &m = *mp;
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;            // groups per block
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long w = (long long)blockIdx.x * GPB + grp;
+    const bool active = w < a.nconf;
+    const long long wr = active ? w : 0;
+    double z[P], F[P], ei[P], E, wf;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+    }
+    eval_walker<G, P, PAD, true, true, ZC>(m, z, gl, lds, F, ei, E, wf);
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < m.n) {
+            if (a.ith) a.ith[w * m.n + i] = ei[p];
+            if (a.drift) a.drift[w * m.n + i] = F[p];
+        }
+    }
+    if (gl == 0) {
+        if (a.wf) a.wf[w] = wf;
+        if (a.energy) a.energy[w] = E;
+    }
+}
+
+// Energy + drift only (no log|psi|, no per-particle energies): the DMC
+// build_state pass (qmc_base/jastrow/dmc.py:1043-1078).
+struct PrepArgs {
+    const double *pos;
+    double *drift, *energy;
+    long long nconf;
+};
+
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
+{
+    // model constants live in device memory: scalar loads on demand keep the
+    // SGPR file free for the hot loop (by-value they overflow it)
+    const DevModel &m = *mp;
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long w = (long long)blockIdx.x * GPB + grp;
+    const bool active = w < a.nconf;
+    const long long wr = active ? w : 0;
+    double z[P], F[P], ei[P], E, wf;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+    }
+    eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, E, wf);
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < m.n) a.drift[w * m.n + i] = F[p];
+    }
+    if (gl == 0) a.energy[w] = E;
+}
+
+// ---- VMC: one launch = one generator yield of every chain ----------------
+// (a step loop inside the kernel lets LICM hoist ~40 polynomial constants and
+// the model constants across it, tripling the register count; with the loop on
+// the host the kernel has the register footprint of `evaluate_kernel` and the
+// state round trip is ~1 KB per chain-step, far below the HBM roofline.)
+struct VmcArgs {
+    double *pos;          // [W][N] in/out, lane (position) order
+    unsigned short *label;// [W][N] in/out, original index of each lane's particle
+    double *wf;           // [W]    in/out  log|psi|
+    double *ecarry;       // [W]    in/out  energy carried to rejected moves
+    double *sum_e, *sum_e2;   // [W] running block sums
+    long long *n_acc;
+    double *ser_wf, *ser_e;   // [nyield][W] or null
+    unsigned char *ser_stat;
+    double *ser_pos;          // [nyield][W][N] or null
+    const double *tape;   // [W][tape_steps][N+1] or null
+    long long tape_steps;
+    long long tape_idx;   // real step index into the tape for this yield
+    long long W;
+    long long y;          // yield index inside the block (series row)
+    int forced;           // this yield is the initial state (ACCEPTED)
+    int reset_sums;       // first yield of a block: sums start from zero
+    int gaussian;
+    unsigned int step;    // Philox step counter of this yield
+    unsigned int chain0;
+    unsigned long long seed;
+    double move_spread;
+};
+
+// LEAN = the production path (Philox uniform proposal, per-chain block sums
+// only); the full variant adds the test-only tape replay, the Gaussian
+// proposal and the per-step series.
+template <int G, int P, bool PAD, bool ZC, bool LEAN>
+__global__ void __launch_bounds__(BLOCK)
+vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
+{
+    const DevModel &m = *mp;
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long w = (long long)blockIdx.x * GPB + grp;
+    const bool active = w < a.W;
+    const long long wr = active ? w : 0;
+    const int n = m.n;
+    const unsigned int slot = a.chain0 + (unsigned int)wr;
+    // The very first yield of a generator is the initial state itself,
+    // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
+    const bool forced = a.forced != 0;
+
+    QMC_SECTION("load+philox+wrap");
+    double zn[P];
+    int labn[P];              // original particle index held by each lane
+    double ua = 1.0;          // accept uniform (particle 0's spare double)
+    double mine = -1.0;       // >= 0 only in the lane that holds particle 0
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        const double zp = (i < n) ? a.pos[wr * n + i] : 0.0;
+        labn[p] = (i < n) ? (int)a.label[wr * n + i] : i;
+        const unsigned li = (unsigned)labn[p];
+        double d = 0.0;
+        if (!forced && i < n) {
+            if (!LEAN && a.tape) {
+                double tv = a.tape[(wr * a.tape_steps + a.tape_idx) * (n + 1) + li];
+                d = a.gaussian ? a.move_spread * tv
+                               : (tv - 0.5) * a.move_spread;
+            } else if (!LEAN && a.gaussian) {
+                double g0, g1;
+                philox_normal2(a.seed, slot, a.step, li, STREAM_VMC_MOVE, g0,
+                               g1);
+                d = a.move_spread * g0;
+            } else {
+                double u0, u1;
+                philox_uniform2(a.seed, slot, a.step, li, STREAM_VMC_MOVE, u0,
+                                u1);
+                d = (u0 - 0.5) * a.move_spread;
+                // the accept draw is the spare double of particle 0
+                mine = (li == 0u) ? u1 : mine;
+            }
+        }
+        // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
+        zn[p] = forced ? zp : wrap_box(zp + d, m.L);
+    }
+    QMC_SECTION("resort");
+    if (!forced) resort_step<G, P>(zn, labn, gl, a.step, n, m.L, m.half_L);
+    double F[P], ei[P], e_new, wf_new;
+    eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
+                                            wf_new);
+    QMC_SECTION("metropolis+store");
+    if (!forced) {
+        if (!LEAN && a.tape) {
+            ua = a.tape[(wr * a.tape_steps + a.tape_idx) * (n + 1) + n];
+        } else if (!LEAN && a.gaussian) {
+            double u1;
+            philox_uniform2(a.seed, slot, a.step, 0u, STREAM_VMC_ACCEPT, ua,
+                            u1);
+        } else {
+            // exactly one lane of the group holds particle 0 (ua >= 0 there):
+            // find it with a ballot and read its value
+            const unsigned long long bal = __ballot(mine >= 0.0);
+            if (G == 64) {
+                const int src = __builtin_amdgcn_readfirstlane(
+                    (int)__ffsll((long long)bal) - 1) & 63;
+                int lo = __double2loint(mine), hi = __double2hiint(mine);
+                lo = __builtin_amdgcn_readlane(lo, src);
+                hi = __builtin_amdgcn_readlane(hi, src);
+                ua = __hiloint2double(hi, lo);
+            } else {
+                const int base = (threadIdx.x & 63) - gl;
+                const unsigned long long grp_bits =
+                    (bal >> base) & ((1ull << (G & 63)) - 1ull);
+                const int src = base + ((__ffsll((long long)grp_bits) - 1) & (G - 1));
+                ua = __shfl(mine, src, 64);
+            }
+        }
+    }
+    if (!active) return;
+    double wf_cur = a.wf[w];
+    double e_cur = a.ecarry[w];
+    // Metropolis test (qmc_base/vmc.py:636)
+    // log(u) <= 0: an uphill move needs no logarithm (wave-uniform when one
+    // wavefront owns one chain)
+    bool acc = forced || ua <= 0.0 || wf_new > wf_cur;
+    if (!acc) acc = wf_new > 0.5 * log_pos(ua) + wf_cur;
+    if (acc) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int i = gl + G * p;
+            if (i < n && !forced) {
+                a.pos[w * n + i] = zn[p];
+                a.label[w * n + i] = (unsigned short)labn[p];
+            }
+        }
+        if (!forced) wf_cur = wf_new;
+        e_cur = e_new;       // energy only re-evaluated on accepted moves
+    }                        // (qmc_base/jastrow/vmc.py:253-262)
+    if (!LEAN && a.ser_pos) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int i = gl + G * p;
+            // series in the original particle order (a rejected move leaves
+            // pos / label as they were: read them back)
+            if (i < n) {
+                const int lb = acc ? labn[p] : (int)a.label[w * n + i];
+                a.ser_pos[(a.y * a.W + w) * n + lb] =
+                    acc ? zn[p] : a.pos[w * n + i];
+            }
+        }
+    }
+    if (gl == 0) {
+        double se = a.reset_sums ? 0.0 : a.sum_e[w];
+        double se2 = a.reset_sums ? 0.0 : a.sum_e2[w];
+        long long na = a.reset_sums ? 0 : a.n_acc[w];
+        a.wf[w] = wf_cur;
+        a.ecarry[w] = e_cur;
+        a.sum_e[w] = se + e_cur;
+        a.sum_e2[w] = fma(e_cur, e_cur, se2);
+        a.n_acc[w] = na + (acc ? 1 : 0);
+        if (!LEAN) {
+            if (a.ser_wf) a.ser_wf[a.y * a.W + w] = wf_cur;
+            if (a.ser_e) a.ser_e[a.y * a.W + w] = e_cur;
+            if (a.ser_stat) a.ser_stat[a.y * a.W + w] = acc ? 1 : 0;
+        }
+    }
+}
+
+// ---- DMC ---------------------------------------------------------------
+// Device-resident control block of a DMC ensemble.
+struct DmcCtl {
+    long long prev_nw;      // walkers in the parent buffer
+    long long nw;           // walkers after branching (this step)
+    double ref_energy;
+    double total_energy, total_weight;
+    double e_t, w_t;        // estimators of this step (local or global)
+    long long spare_nw;     // slots holding a valid spare normal
+    unsigned int step;
+    unsigned int pad;
+};
+
+struct EvolveArgs {
+    const double *ppos, *pdrift, *penergy;   // parents
+    double *cpos, *cdrift, *cenergy, *cweight; // children
+    const unsigned short *plabel;             // parents' lane -> particle index
+    unsigned short *clabel;
+    double *eslot;            // energy the slot held in the previous iteration
+    const long long *ref;
+    const DmcCtl *ctl;
+    const double *g_tape;     // [slot][N] standard normals or null
+    double *spare;            // [maxw][N] second Box-Muller normal of a pair
+    long long maxw;
+    double dt, sigma;
+    unsigned long long seed;
+    unsigned int slot0;
+    int fix_stale;
+};
+
+// Drift-diffusion + local energy of every child walker
+// (qmc_base/jastrow/dmc.py:758-825, 892-942).
+template <int G, int P, bool PAD, bool ZC>
+__global__ void __launch_bounds__(BLOCK)
+dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
+{
+    // model constants live in device memory: scalar loads on demand keep the
+    // SGPR file free for the hot loop (by-value they overflow it)
+    const DevModel &m = *mp;
+    extern __shared__ double smem[];
+    constexpr int GPB = BLOCK / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    const long long s = (long long)blockIdx.x * GPB + grp;
+    const long long nw = a.ctl->nw;
+    // whole block beyond the population: nothing to do
+    if ((long long)blockIdx.x * GPB >= nw) return;
+    const bool active = s < nw;
+    const long long sr = active ? s : 0;
+    const int n = m.n;
+    const unsigned int step = a.ctl->step;
+    const double ref_energy = a.ctl->ref_energy;
+    // slots that existed at the previous (even) step have a stored normal
+    const long long spare_nw = a.ctl->spare_nw;
+    const long long par = a.ref[sr];
+
+    double z[P];
+    int lab[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        double zz = 0.0;
+        lab[p] = i;
+        if (i < n) {
+            double z0 = a.ppos[par * n + i];
+            double f0 = a.pdrift[par * n + i];
+            // random numbers belong to the particle (label), not to the lane
+            const int li = (int)a.plabel[par * n + i];
+            lab[p] = li;
+            double g;
+            if (a.g_tape) {
+                g = a.g_tape[sr * n + li];
+            } else if ((step & 1u) && sr < spare_nw) {
+                // odd step: the sine-branch normal stored by the even step
+                g = a.spare[sr * n + li];
+            } else {
+                // time steps 2m, 2m+1 share one Philox block: cosine branch
+                // now, sine branch kept for the next step of this slot
+                double g0, g1;
+                philox_normal2(a.seed, a.slot0 + (unsigned)sr, step >> 1,
+                               (unsigned)li, STREAM_DMC_DIFFUSE, g0, g1);
+                g = (step & 1u) ? g1 : g0;
+                if (!(step & 1u) && active) a.spare[sr * n + li] = g1;
+            }
+            // ith_diffusion (qmc_base/jastrow/dmc.py:661-671)
+            double zn = z0 + 2 * f0 * a.dt + a.sigma * g;
+            zz = wrap_box(zn, m.L);
+        }
+        z[p] = zz;
+    }
+    resort_step<G, P>(z, lab, gl, step, n, m.L, m.half_L);
+    // positions and labels leave now: not live across the pair sum
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (active && i < n) {
+            a.cpos[s * n + i] = z[p];
+            a.clabel[s * n + i] = (unsigned short)lab[p];
+        }
+    }
+    double F[P], ei[P], e_next, wf;
+    eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, e_next, wf);
+    if (!active) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int i = gl + G * p;
+        if (i < n) a.cdrift[s * n + i] = F[p];
+    }
+    if (gl == 0) {
+        double e_par = a.penergy[par];
+        // the reference averages with the energy slot s held in
+        // the previous iteration (jastrow/dmc.py:810), not the parent's.
+        double e_old = a.fix_stale ? e_par : a.eslot[s];
+        double mean_energy = (e_next + e_old) / 2;
+        a.cenergy[s] = e_next;
+        a.cweight[s] = exp(-a.dt * (mean_energy - ref_energy));
+        a.eslot[s] = e_par;
+    }
+}

@@ -12,17 +12,28 @@ What is exchanged, and why only that:
   walkers (`step_local`), leaves (E_t, W_t) in a 2-double device buffer, the
   buffer is all-reduced in place (16 bytes, latency-bound; xGMI bandwidth is
   irrelevant), and `step_finish` applies the feedback with the global sums --
-  every rank computes the same E_ref.  All three are enqueued on one stream,
-  so the host runs ahead of the device and never synchronises inside a block.
+  every rank computes the same E_ref.  All three are enqueued on ONE stream
+  (the engine must have been created on the stream torch is using:
+  `ModelEngine(..., stream=torch.cuda.current_stream().cuda_stream)`; checked
+  here), so the collective is ordered after `step_local` and before
+  `step_finish` by the stream itself, the host runs ahead of the device and
+  never synchronises inside a block.
 * Local populations random-walk apart, so every `rebalance_every` steps the
-  ranks all-gather their counts, derive the same greedy plan (ranks above the
-  mean send their tail walkers to ranks below it) and move whole walker
-  records (pos, drift, lane labels, energy, weight: 3N+2 doubles) with point-to-point
-  send/recv -- single hop on the fully connected xGMI mesh.
+  ranks all-gather their counts (the one host synchronisation of a
+  rebalance), derive the same greedy plan (ranks above the mean send their
+  tail walkers to ranks below it) and move whole walker records (pos, drift,
+  lane labels, energy, weight and the walker's forward-walking estimator rows)
+  with point-to-point send/recv -- single hop on the fully connected xGMI
+  mesh.  Packing, transfer, unpacking and the new population size are all
+  stream-ordered.
+* The S(k) / density estimators are sums over walkers: every rank evaluates
+  them on its own walkers (`step_estimators`) and the per-step rows are
+  all-reduced once per block.
 
 The reference has no distributed path at all; its global cap
 `max_num_walkers` becomes a per-rank cap max_num_walkers / world here.
 """
+import ctypes as C
 import typing as t
 
 import numpy as np
@@ -61,6 +72,25 @@ def rebalance_plan(counts: t.Sequence[int]) -> t.List[t.Tuple[int, int, int]]:
         if deficit[j][1] == 0:
             j += 1
     return plan
+
+
+class _RawDeviceArray:
+    """A device address as a zero-copy torch tensor source
+    (`__cuda_array_interface__`; ROCm builds of torch use the same name)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {
+            'shape': (int(count),), 'typestr': '<f8',
+            'data': (int(ptr), False), 'version': 2, 'strides': None}
+
+
+def _wrap_f64(ptr: int, count: int, device: torch.device) -> torch.Tensor:
+    """View `count` doubles at address `ptr` as a tensor on `device`."""
+    if device.type == 'cuda':
+        return torch.as_tensor(_RawDeviceArray(ptr, count), device=device)
+    arr = np.ctypeslib.as_array(
+        C.cast(ptr, C.POINTER(C.c_double)), shape=(int(count),))
+    return torch.from_numpy(arr)
 
 
 class DistributedVmc:
@@ -107,9 +137,30 @@ class DistributedDmc:
         self.rank, self.world = _world()
         self.rebalance_every = int(rebalance_every)
         self.imbalance_tol = float(imbalance_tol)
+        self._check_stream()
         self.sums = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.steps_done = 0
         self.walkers_moved = 0
+        self.rebalances = 0
+        self._inflight = []      # transfer buffers of the last rebalance
+
+    def _check_stream(self):
+        """The collectives are ordered with the engine's kernels only when
+        both use the same stream."""
+        if self.device.type != 'cuda':
+            return
+        engine = getattr(self.ens, 'engine', None)
+        if engine is None:
+            return
+        mine = int(engine.stream_handle)
+        theirs = int(torch.cuda.current_stream(self.device).cuda_stream)
+        if mine != theirs:
+            raise RuntimeError(
+                f'DistributedDmc: the engine launches on stream {mine:#x} but '
+                f'torch.cuda.current_stream() is {theirs:#x}; create the '
+                f'engine with stream=torch.cuda.current_stream().cuda_stream '
+                f'(and keep that stream current) so that RCCL collectives are '
+                f'ordered with the walker kernels')
 
     # the handle gets raw addresses; tensors stay alive on self
     def _ptr(self, tensor):
@@ -123,21 +174,48 @@ class DistributedDmc:
         self.ens.step_finish(self._ptr(self.sums))
         self.steps_done += 1
 
-    def run_block(self, num_steps: int):
+    def run_block(self, num_steps: int, estimators: bool = False):
         """`num_steps` time steps with periodic population rebalance;
-        -> the per-step series (global E_t, W_t; local walker counts)."""
-        for _ in range(int(num_steps)):
+        -> the per-step series (global E_t, W_t; local walker counts), and
+        with `estimators` also (iter_ssf[num_steps, M, 3] or None,
+        iter_density[num_steps, B] or None) summed over all ranks."""
+        num_steps = int(num_steps)
+        if estimators:
+            self.ens.est_begin_block(num_steps)
+        for t_idx in range(num_steps):
             if (self.world > 1 and self.rebalance_every > 0 and
                     self.steps_done % self.rebalance_every == 0 and
                     self.steps_done > 0):
                 self.rebalance()
             self.step()
-        return self.ens.read_series(int(num_steps))
+            if estimators:
+                self.ens.step_estimators(t_idx)
+        if not estimators:
+            return self.ens.read_series(num_steps)
+        ssf, dens = self._reduce_estimators(num_steps)
+        return self.ens.read_series(num_steps), ssf, dens
+
+    def _reduce_estimators(self, num_steps: int):
+        M = int(getattr(self.ens, 'num_modes', 0))
+        B = int(getattr(self.ens, 'num_bins', 0))
+        p_ssf, p_dens = self.ens.est_iter_dev()
+        out = []
+        for ptr, cnt, shape in ((p_ssf, num_steps * M * 3, (num_steps, M, 3)),
+                                (p_dens, num_steps * B, (num_steps, B))):
+            if not ptr or not cnt:
+                out.append(None)
+                continue
+            view = _wrap_f64(ptr, cnt, self.device)
+            if self.world > 1:
+                dist.all_reduce(view)           # in place, engine's stream
+            out.append(view.cpu().numpy().reshape(shape).copy())
+        return out[0], out[1]
 
     def local_count(self) -> int:
         return int(self.ens.num_walkers())
 
     def global_counts(self) -> t.List[int]:
+        """Synchronising: reads the device walker count."""
         if self.world == 1:
             return [self.local_count()]
         mine = torch.tensor([self.local_count()], dtype=torch.int64,
@@ -146,19 +224,24 @@ class DistributedDmc:
         dist.all_gather(allc, mine)
         return [int(c.item()) for c in allc]
 
+    def record_size(self) -> int:
+        f = getattr(self.ens, 'walker_record_size', None)
+        return int(f()) if f is not None else 3 * self.n + 2
+
     def rebalance(self, force: bool = False) -> int:
         """Level the local populations; -> number of walkers this rank sent
-        or received.  Synchronising (reads the device walker count)."""
+        or received.  One host synchronisation (the walker counts); packing,
+        transfers, unpacking and the new population size are stream-ordered."""
         counts = self.global_counts()
         mean = sum(counts) / len(counts)
         if not force and mean > 0 and \
                 (max(counts) - min(counts)) <= self.imbalance_tol * mean:
             return 0
         plan = rebalance_plan(counts)
-        rec = 3 * self.n + 2
+        rec = self.record_size()
         moved = 0
         nw = counts[self.rank]
-        ops, bufs = [], []
+        ops, recvs, keep = [], [], []
         for src, dst, cnt in plan:
             if src == self.rank:
                 buf = torch.empty(cnt * rec, dtype=torch.float64,
@@ -167,23 +250,28 @@ class DistributedDmc:
                 self.ens.export_walkers(nw - cnt, cnt, self._ptr(buf))
                 nw -= cnt
                 ops.append(dist.P2POp(dist.isend, buf, dst))
-                bufs.append((None, buf, cnt))
+                keep.append(buf)
                 moved += cnt
             elif dst == self.rank:
                 buf = torch.empty(cnt * rec, dtype=torch.float64,
                                   device=self.device)
                 ops.append(dist.P2POp(dist.irecv, buf, src))
-                bufs.append(('recv', buf, cnt))
+                recvs.append((buf, cnt))
+                keep.append(buf)
                 moved += cnt
-        if self.device.type == 'cuda':
-            torch.cuda.current_stream().synchronize()   # packed before send
         if ops:
+            # RCCL: the transfers wait for the packing kernels through the
+            # current stream, and wait() makes that stream wait for them
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if nw != counts[self.rank]:
-            self.ens.truncate(nw)
-        for kind, buf, cnt in bufs:
-            if kind == 'recv':
-                self.ens.import_walkers(cnt, self._ptr(buf))
+            self.ens.set_num_walkers(nw)
+        for buf, cnt in recvs:
+            self.ens.import_walkers_at(nw, cnt, self._ptr(buf))
+            nw += cnt
+        # the unpack kernels read the buffers asynchronously: keep them until
+        # the next rebalance (by then the stream has long passed them)
+        self._inflight = keep
         self.walkers_moved += moved
+        self.rebalances += 1 if moved else 0
         return moved

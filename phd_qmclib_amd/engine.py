@@ -100,7 +100,14 @@ class DeviceBuffer:
 
 
 class ModelEngine:
-    """Model constants bound to one GPU + stream (qmc_engine)."""
+    """Model constants bound to one GPU + stream (qmc_engine).
+
+    `stream=None`: the engine creates its own non-blocking stream.
+    `stream=<int>`: the caller's hipStream_t handle, used as it is -- 0 is the
+    legacy default stream, which is what `torch.cuda.current_stream()
+    .cuda_stream` returns unless a side stream is current.  Pass the stream
+    torch is using whenever torch.distributed (RCCL) collectives must be
+    ordered with the engine's kernels (`dist.DistributedDmc` checks it)."""
 
     def __init__(self, cfc_spec, device: t.Optional[int] = None,
                  stream: t.Optional[int] = None):
@@ -110,10 +117,43 @@ class ModelEngine:
         self.device = _current_device() if device is None else int(device)
         self._params = model_params_struct(cfc_spec)
         h = C.c_void_p()
-        check(self._lib.qmc_engine_create(C.byref(self._params), self.device,
-                                          C.c_void_p(stream or 0),
-                                          C.byref(h)))
+        if stream is None:
+            check(self._lib.qmc_engine_create(C.byref(self._params),
+                                              self.device, None, C.byref(h)))
+        else:
+            check(self._lib.qmc_engine_create_on_stream(
+                C.byref(self._params), self.device, C.c_void_p(int(stream)),
+                C.byref(h)))
         self._h = h
+
+    @property
+    def stream_handle(self) -> int:
+        """hipStream_t the engine launches on (0 = legacy default stream)."""
+        st, owned = C.c_void_p(), C.c_int(0)
+        check(self._lib.qmc_engine_stream(self._h, C.byref(st),
+                                          C.byref(owned)))
+        return int(st.value or 0)
+
+    @property
+    def owns_stream(self) -> bool:
+        st, owned = C.c_void_p(), C.c_int(0)
+        check(self._lib.qmc_engine_stream(self._h, C.byref(st),
+                                          C.byref(owned)))
+        return bool(owned.value)
+
+    def profile_begin(self, max_launches: int = 4096):
+        """Start timing every launch of the dominant kernel (one HIP event
+        pair each, on the engine's stream)."""
+        check(self._lib.qmc_engine_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        """-> (launches, total_ms, min_ms, max_ms); synchronises."""
+        n = C.c_int64(0)
+        tot, mn, mx = C.c_double(0), C.c_double(0), C.c_double(0)
+        check(self._lib.qmc_engine_profile_end(self._h, C.byref(n),
+                                               C.byref(tot), C.byref(mn),
+                                               C.byref(mx)))
+        return int(n.value), float(tot.value), float(mn.value), float(mx.value)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -323,11 +363,14 @@ class DmcEnsemble:
             float(ref_energy if ref_energy is not None else 0.0)))
 
     def set_state_from_vmc(self, vmc: 'VmcEnsemble', num_walkers=None,
-                           ref_energy: t.Optional[float] = None):
+                           ref_energy: t.Optional[float] = None,
+                           replicate: bool = False):
         """build_state from the current configurations of a VMC ensemble on
-        the same engine, device to device (the first `num_walkers` chains)."""
+        the same engine, device to device (the first `num_walkers` chains;
+        with `replicate` more walkers than chains are allowed and the chains
+        are reused cyclically)."""
         nw = vmc.num_chains if num_walkers is None else int(num_walkers)
-        if nw > vmc.num_chains:
+        if nw > vmc.num_chains and not replicate:
             raise ValueError('more walkers requested than chains')
         self.engine.sync()
         check(self._lib.qmc_dmc_set_state_from_vmc(
@@ -419,6 +462,15 @@ class DmcEnsemble:
                         float(sc[0]), float(sc[1]), float(sc[2]),
                         float(sc[3]), int(sc[4]))
 
+    def get_scalars(self):
+        """-> (state_energy, state_weight, ref_energy, accum_energy,
+        num_walkers) without downloading the population."""
+        sc = np.zeros(5)
+        check(self._lib.qmc_dmc_get_state(self._h, None, None, None, None,
+                                          None, ptr(sc)))
+        return (float(sc[0]), float(sc[1]), float(sc[2]), float(sc[3]),
+                int(sc[4]))
+
     # -- multi-GPU building blocks ------------------------------------------
     def step_local(self, partial_ptr: int):
         check(self._lib.qmc_dmc_step_local(self._h, partial_ptr))
@@ -431,12 +483,44 @@ class DmcEnsemble:
         check(self._lib.qmc_dmc_num_walkers(self._h, C.byref(n)))
         return int(n.value)
 
+    def walker_record_size(self) -> int:
+        """Doubles per walker record of export / import (3N + 2 + the
+        forward-walking estimator rows when estimators are set)."""
+        n = C.c_int64(0)
+        check(self._lib.qmc_dmc_walker_record_size(self._h, C.byref(n)))
+        return int(n.value)
+
     def export_walkers(self, first: int, count: int, buf_ptr: int):
         check(self._lib.qmc_dmc_export_walkers(self._h, int(first), int(count),
                                                buf_ptr))
 
     def import_walkers(self, count: int, buf_ptr: int):
+        """Append at the device's population count (synchronises)."""
         check(self._lib.qmc_dmc_import_walkers(self._h, int(count), buf_ptr))
+
+    def import_walkers_at(self, first: int, count: int, buf_ptr: int):
+        """Stream-ordered: records -> slots [first, first + count); the
+        population size becomes first + count."""
+        check(self._lib.qmc_dmc_import_walkers_at(self._h, int(first),
+                                                  int(count), buf_ptr))
+
+    def set_num_walkers(self, nw: int):
+        """Stream-ordered truncation (the caller knows the population size)."""
+        check(self._lib.qmc_dmc_set_num_walkers(self._h, int(nw)))
 
     def truncate(self, new_nw: int):
         check(self._lib.qmc_dmc_truncate(self._h, int(new_nw)))
+
+    # -- estimators of a split-step (multi-GPU) run -------------------------
+    def est_begin_block(self, nsteps: int):
+        check(self._lib.qmc_dmc_est_begin_block(self._h, int(nsteps)))
+
+    def step_estimators(self, step_idx: int):
+        check(self._lib.qmc_dmc_step_estimators(self._h, int(step_idx)))
+
+    def est_iter_dev(self):
+        """Device addresses (ints or None) of this rank's iter_ssf /
+        iter_density rows of the open estimator block."""
+        a, b = C.c_void_p(), C.c_void_p()
+        check(self._lib.qmc_dmc_est_iter_dev(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,35 @@
+"""CPU stand-in backend for the launcher test of bench.py (selected with
+QMC_BENCH_BACKEND=tests._bench_standin).  TEST INFRASTRUCTURE: the population
+handle is the oracle-backed look-alike of tests/_dist_worker.py and the
+process group is gloo; it exists so that `bench.py --gpus 2` (rank spawning,
+rendezvous, the sharded-DMC host logic and the JSON line) can be exercised
+without a GPU.  bench.py never selects it by itself."""
+import numpy as np
+import torch
+
+from bench import box_spec
+from oracle import qmc_oracle as orc
+from phd_qmclib_amd.dist import DistributedDmc
+from tests._dist_worker import OracleShard
+
+
+class Backend:
+    dist_backend = 'gloo'
+    has_vmc = False
+
+    def __init__(self, local_rank):
+        self.local_rank = local_rank
+        self.device = torch.device('cpu')
+
+    def sync(self):
+        pass
+
+    def sharded_population(self, n, per_rank, cap, global_target, rank, world,
+                           equil, rebalance_every):
+        model = orc.model_from_cfc(box_spec(n).cfc_spec)
+        rng = np.random.RandomState(100 + rank)
+        pos = n * rng.random_sample((per_rank, n))
+        shard = OracleShard(orc, model, pos, 6.25e-4, cap, global_target, 0.5,
+                            seed=1, slot0=rank * cap)
+        dd = DistributedDmc(shard, n, 'cpu', rebalance_every=rebalance_every)
+        return shard, dd, None, per_rank

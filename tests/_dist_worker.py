@@ -76,21 +76,30 @@ class OracleShard:
         out[:, 3 * self.n] = en[first:first + count]
         out[:, 3 * self.n + 1] = wt[first:first + count]
 
-    def import_walkers(self, count, buf_ptr):
+    def walker_record_size(self):
+        return 3 * self.n + 2
+
+    def import_walkers_at(self, first, count, buf_ptr):
         confs, en, wt = self._pop()
         rec = 3 * self.n + 2
         src = self._view(buf_ptr, (count, rec))
-        nw = self.num_walkers()
-        assert nw + count <= self.maxw
-        confs[nw:nw + count, 0] = src[:, :self.n]
-        confs[nw:nw + count, 1] = src[:, self.n:2 * self.n]
-        en[nw:nw + count] = src[:, 3 * self.n]
-        wt[nw:nw + count] = src[:, 3 * self.n + 1]
-        self.ens.st.prev_num_walkers = nw + count
+        assert first + count <= self.maxw
+        confs[first:first + count, 0] = src[:, :self.n]
+        confs[first:first + count, 1] = src[:, self.n:2 * self.n]
+        en[first:first + count] = src[:, 3 * self.n]
+        wt[first:first + count] = src[:, 3 * self.n + 1]
+        self.ens.st.prev_num_walkers = first + count
+
+    def import_walkers(self, count, buf_ptr):
+        self.import_walkers_at(self.num_walkers(), count, buf_ptr)
+
+    def set_num_walkers(self, new_nw):
+        assert 0 <= new_nw <= self.maxw
+        self.ens.st.prev_num_walkers = new_nw
 
     def truncate(self, new_nw):
         assert 0 <= new_nw <= self.num_walkers()
-        self.ens.st.prev_num_walkers = new_nw
+        self.set_num_walkers(new_nw)
 
     def fingerprint(self):
         confs, en, wt = self._pop()

@@ -1,0 +1,54 @@
+"""bench.py spawns its own ranks: `python bench.py --gpus 2` (no RANK in the
+environment) must run TWO ranks that join one process group and print ONE JSON
+line whose n_gpus is the world size the process group reports.  On CPU the
+GPU backend is replaced by the gloo / oracle stand-in of tests/_bench_standin
+(host logic only; the GPU numbers come from the driver's runs)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+
+def run_bench(args, env_extra, timeout=240):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
+                        'MASTER_PORT')}
+    env.update(env_extra)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] +
+                          args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.timeout(300)
+def test_bench_spawns_two_ranks(oracle):
+    r = run_bench(['--gpus', '2', '--steps', '6', '--warmup', '2',
+                   '--c4-bosons', '8', '--c4-walkers', '48',
+                   '--rebalance-every', '2', '--no-checks'],
+                  {'QMC_BENCH_BACKEND': 'tests._bench_standin'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2                       # two ranks joined
+    assert out['scaling'] == 'strong'
+    assert out['metric'] == 'walker-steps/sec' and out['value'] > 0
+    assert out['steps'] == 6 and out['warmup'] == 2
+    assert out['config']['global_target_walkers'] == 48
+    assert out['config']['walkers_per_gpu'] == 24
+    # W_t of every step is the sum over BOTH ranks: about the global target
+    assert 30 < out['extra']['mean_walkers'] < 70
+    assert 'cpu_baseline' not in out                # rank 0 at N = 1 only
+
+
+def test_bench_refuses_world_size_mismatch():
+    # a single process told --gpus 2 by a launcher that started one rank
+    r = run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1'],
+                  {'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0',
+                   'QMC_BENCH_BACKEND': 'tests._bench_standin'})
+    assert r.returncode != 0
+    assert 'WORLD_SIZE' in r.stderr

@@ -1,0 +1,212 @@
+"""GPU tests of the multi-GPU building blocks on ONE device (world size 1 and
+two in-process shards): stream sharing with torch, the split-step estimators,
+and the population rebalance (walker records carry the forward-walking rows,
+spare normals are not inherited, everything is stream-ordered)."""
+from math import pi
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def box(n=16, **kw):
+    from phd_qmclib_amd import mrbp_qmc
+    args = dict(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                interaction_strength=2, boson_number=n, supercell_size=n,
+                tbf_contact_cutoff=0.25 * n)
+    args.update(kw)
+    return mrbp_qmc.Spec(**args)
+
+
+def test_engine_launches_on_the_callers_stream():
+    """`stream=0` used to mean "create my own stream", so an
+    engine handed torch's default stream silently ran beside it."""
+    import torch
+    from phd_qmclib_amd.dist import DistributedDmc
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    cfc = box(16).cfc_spec
+    cur = torch.cuda.current_stream().cuda_stream      # 0: legacy default
+    e0 = ModelEngine(cfc, stream=cur)
+    assert e0.stream_handle == cur and not e0.owns_stream
+    own = ModelEngine(cfc)
+    assert own.owns_stream and own.stream_handle != 0
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        e1 = ModelEngine(cfc, stream=side.cuda_stream)
+        assert e1.stream_handle == side.cuda_stream != 0
+        d = DmcEnsemble(e1, 1e-3, 128, 64, 0.5, rng_seed=1,
+                        external_reduce=True)
+        DistributedDmc(d, 16, 'cuda')                  # same stream: accepted
+        d2 = DmcEnsemble(own, 1e-3, 128, 64, 0.5, rng_seed=1,
+                         external_reduce=True)
+        with pytest.raises(RuntimeError, match='stream'):
+            DistributedDmc(d2, 16, 'cuda')             # engine's own stream
+        d.close()
+        d2.close()
+    for e in (e0, own, e1):
+        e.close()
+
+
+def _ensembles(n, nw, maxw, seed, est, **kw):
+    import torch
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    eng = ModelEngine(box(n).cfc_spec,
+                      stream=torch.cuda.current_stream().cuda_stream)
+    pos = n * np.random.RandomState(seed).random_sample((nw, n))
+    d = DmcEnsemble(eng, 1e-3, maxw, nw, 0.5, rng_seed=seed, **kw)
+    if est:
+        d.set_estimators(**est)
+    d.set_state(pos)
+    return eng, d
+
+
+EST = dict(num_modes=12, ssf_pure=True, ssf_pfw=24, num_bins=16,
+           dens_pure=True, dens_pfw=24)
+
+
+def test_split_step_estimators_equal_run_block_est():
+    from phd_qmclib_amd.dist import DistributedDmc
+    eng_a, a = _ensembles(16, 200, 256, 3, EST)
+    eng_b, b = _ensembles(16, 200, 256, 3, EST, external_reduce=True)
+    for blk in range(2):                 # per-block resets included
+        sa, ssf_a, dens_a = a.run_block_est(20)
+        dd = DistributedDmc(b, 16, 'cuda') if blk == 0 else dd
+        sb, ssf_b, dens_b = dd.run_block(20, estimators=True)
+        assert np.array_equal(sa.energy, sb.energy)
+        assert np.array_equal(sa.num_walkers, sb.num_walkers)
+        assert np.array_equal(ssf_a, ssf_b)
+        assert np.array_equal(dens_a[..., 0], dens_b)
+    assert np.abs(ssf_a).max() > 0
+    for h in (a, b, eng_a, eng_b):
+        h.close()
+
+
+@pytest.mark.parametrize('when', [7, 8])        # odd and even step counts
+def test_rebalance_round_trip_is_exact(when):
+    """Export the tail walkers, drop them, import them back in the middle of
+    a block with PURE (forward-walking) estimators: every later number must be
+    bit-identical to the undisturbed run -- i.e. the walker record carries
+    everything a walker owns (positions, drift, lane labels, energy, weight,
+    its S(k) and density rows) and an imported slot does not consume a stale
+    spare normal."""
+    import torch
+    from phd_qmclib_amd.dist import DistributedDmc
+    res = []
+    for disturb in (False, True):
+        eng, d = _ensembles(24, 150, 256, 11, EST, external_reduce=True)
+        dd = DistributedDmc(d, 24, 'cuda', rebalance_every=0)
+        d.est_begin_block(20)
+        for t in range(20):
+            if disturb and t == when:
+                nw = d.num_walkers()
+                k = 37
+                rec = d.walker_record_size()
+                assert rec == 3 * 24 + 2 + 3 * 12 + 16
+                buf = torch.zeros(k * rec, dtype=torch.float64, device='cuda')
+                d.export_walkers(nw - k, k, buf.data_ptr())
+                d.set_num_walkers(nw - k)
+                d.import_walkers_at(nw - k, k, buf.data_ptr())
+            dd.step()
+            d.step_estimators(t)
+        ssf, dens = dd._reduce_estimators(20)
+        ser = d.read_series(20)
+        res.append((ser, ssf, dens))
+        d.close()
+        eng.close()
+    (s0, ssf0, den0), (s1, ssf1, den1) = res
+    assert np.array_equal(s0.num_walkers, s1.num_walkers)
+    assert np.array_equal(s0.energy, s1.energy)
+    assert np.array_equal(s0.ref_energy, s1.ref_energy)
+    assert np.array_equal(ssf0, ssf1)
+    assert np.array_equal(den0, den1)
+    assert np.abs(ssf0[-1]).max() > 0 and den0[-1].sum() > 0
+
+
+def _fingerprint(h, count):
+    """Energies of the first `count` walkers of the CURRENT population."""
+    import torch
+    rec = h.walker_record_size()
+    buf = torch.zeros(count * rec, dtype=torch.float64, device='cuda')
+    h.export_walkers(0, count, buf.data_ptr())
+    h.engine.sync()
+    return buf.cpu().numpy().reshape(count, rec)[:, 3 * h.num_particles]
+
+
+def test_two_shards_one_population():
+    """Two handles on one GPU driven as two ranks of one population: the
+    E_ref feedback sees the global sums, a transfer conserves the walkers and
+    the mixed S(k) of the union is the sum of the shards' (linearity)."""
+    import torch
+    eng, a = _ensembles(16, 90, 160, 21, dict(num_modes=8),
+                        external_reduce=True, slot0=0)
+    pos_b = 16 * np.random.RandomState(22).random_sample((30, 16))
+    from phd_qmclib_amd.engine import DmcEnsemble
+    b = DmcEnsemble(eng, 1e-3, 160, 90, 0.5, rng_seed=21, slot0=160,
+                    external_reduce=True)
+    b.set_estimators(num_modes=8)
+    b.set_state(pos_b)
+    # one target (120) and one E_ref for both shards
+    ea, eb = a.get_scalars()[2], b.get_scalars()[2]
+    ref = (90 * ea + 30 * eb) / 120
+    pos_a = 16 * np.random.RandomState(21).random_sample((90, 16))
+    for h, p in ((a, pos_a), (b, pos_b)):
+        h.close()
+    a = DmcEnsemble(eng, 1e-3, 160, 120, 0.5, rng_seed=21, slot0=0,
+                    external_reduce=True)
+    b = DmcEnsemble(eng, 1e-3, 160, 120, 0.5, rng_seed=21, slot0=160,
+                    external_reduce=True)
+    for h, p in ((a, pos_a), (b, pos_b)):
+        h.set_estimators(num_modes=8)
+        h.set_state(p, ref_energy=ref)
+    pa = torch.zeros(2, dtype=torch.float64, device='cuda')
+    pb = torch.zeros(2, dtype=torch.float64, device='cuda')
+    tot = torch.zeros(2, dtype=torch.float64, device='cuda')
+    nsteps = 12
+    for h in (a, b):
+        h.est_begin_block(nsteps)
+    for t in range(nsteps):
+        if t == 5:
+            # level 90-ish / 30-ish: move 30 tail walkers from a to b
+            na, nb = a.num_walkers(), b.num_walkers()
+            fp = sorted(np.concatenate([_fingerprint(a, na),
+                                        _fingerprint(b, nb)]))
+            k = 30
+            buf = torch.zeros(k * a.walker_record_size(), dtype=torch.float64,
+                              device='cuda')
+            a.export_walkers(na - k, k, buf.data_ptr())
+            a.set_num_walkers(na - k)
+            b.import_walkers_at(nb, k, buf.data_ptr())
+            assert a.num_walkers() == na - k and b.num_walkers() == nb + k
+            fp2 = sorted(np.concatenate([_fingerprint(a, na - k),
+                                         _fingerprint(b, nb + k)]))
+            assert fp == fp2
+        a.step_local(pa.data_ptr())
+        b.step_local(pb.data_ptr())
+        torch.add(pa, pb, out=tot)
+        a.step_finish(tot.data_ptr())
+        b.step_finish(tot.data_ptr())
+        a.step_estimators(t)
+        b.step_estimators(t)
+    sa, sb = a.read_series(nsteps), b.read_series(nsteps)
+    # both shards hold the same global series; W_t = sum of the local counts
+    assert np.array_equal(sa.energy, sb.energy)
+    assert np.array_equal(sa.ref_energy, sb.ref_energy)
+    assert np.array_equal(sa.weight,
+                          (sa.num_walkers + sb.num_walkers).astype(float))
+    # linearity of the mixed S(k): shards' rows add up to the union's
+    from phd_qmclib_amd.dist import _wrap_f64
+    dev = torch.device('cuda')
+    rows = [_wrap_f64(h.est_iter_dev()[0], nsteps * 8 * 3, dev).cpu().numpy()
+            .reshape(nsteps, 8, 3) for h in (a, b)]
+    sta, stb = a.get_state(), b.get_state()
+    confs = np.concatenate([sta.confs[:sta.num_walkers, 0],
+                            stb.confs[:stb.num_walkers, 0]])
+    k = 2 * np.pi * np.arange(8) / 16
+    ph = confs[:, None, :] * k[None, :, None]
+    re, im = np.cos(ph).sum(-1), np.sin(ph).sum(-1)
+    want = np.stack([re * re + im * im, re, im], axis=-1).sum(0)
+    got = rows[0][-1] + rows[1][-1]
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-7)
+    for h in (a, b, eng):
+        h.close()
