@@ -107,6 +107,15 @@ const char *qmc_last_error(void);
 int qmc_abi_version(void);
 int qmc_device_count(int *count);
 
+/* Diagnostic (no GPU needed): the piecewise-polynomial table of the one-body
+ * factor (mrbp_qmc/model.py:404-464: f1'/f1 and log f1 inside the unit cell)
+ * the kernels would use for this model: intervals over the well and over the
+ * barrier (0, 0 = the closed forms are evaluated directly) and the worst
+ * deviation from the closed forms found while building it. */
+int qmc_model_one_body_table_info(const qmc_model_params *model,
+                                  int32_t *rows_well, int32_t *rows_barrier,
+                                  double *max_err);
+
 /* ---- engine: model constants on one device --------------------------- */
 int qmc_engine_create(const qmc_model_params *model, int device, void *stream,
                       qmc_engine **out);
@@ -115,6 +124,16 @@ int qmc_engine_create_on_stream(const qmc_model_params *model, int device,
 void qmc_engine_destroy(qmc_engine *eng);
 /* the stream the engine launches on; *owned = 1 if the engine created it */
 int qmc_engine_stream(qmc_engine *eng, void **stream, int *owned);
+/* The reference's reduced-precision knob, `jit_fastmath`
+ * (mrbp_qmc/dmc.py:159-160; qmc_base/jastrow/dmc.py `fastmath=`): with on != 0
+ * the O(N^2) pair loop (products of the per-particle sin/cos tables, the
+ * quotient per pair, the pair sums) runs in float; positions, the tables
+ * themselves, the one-body factor, the energy assembly, the logarithms and
+ * the Metropolis test stay in double.  Off by default; relative error of the
+ * local energy ~1e-6 (tests/test_gpu_fastmath.py reports it).  *in_effect
+ * tells whether the engine has the variant for its model (boson_number > 32,
+ * cutoff not close to L/2); where it has not, the call changes nothing. */
+int qmc_engine_set_fast_math(qmc_engine *eng, int on, int *in_effect);
 int qmc_engine_sync(qmc_engine *eng);
 /* HIP-event timing on the engine's stream (bench / roofline) */
 int qmc_engine_timer_start(qmc_engine *eng);

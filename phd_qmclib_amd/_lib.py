@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libqmcwalk.so')
+# (QMCWALK_LIB: development knob to A/B another build of the same library)
+LIB_PATH = os.environ.get('QMCWALK_LIB') or os.path.join(_HERE, 'libqmcwalk.so')
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
@@ -65,11 +66,15 @@ SIGNATURES = {
     'qmc_last_error': (C.c_char_p, []),
     'qmc_abi_version': (C.c_int, []),
     'qmc_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'qmc_model_one_body_table_info': (C.c_int, [C.POINTER(ModelParams),
+                                                C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_int32), _dp]),
     'qmc_engine_create': (C.c_int, [C.POINTER(ModelParams), C.c_int, _vp,
                                     C.POINTER(_vp)]),
     'qmc_engine_create_on_stream': (C.c_int, [C.POINTER(ModelParams), C.c_int,
                                               _vp, C.POINTER(_vp)]),
     'qmc_engine_destroy': (None, [_vp]),
+    'qmc_engine_set_fast_math': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     'qmc_engine_stream': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
     'qmc_engine_profile_begin': (C.c_int, [_vp, C.c_int64]),
     'qmc_engine_profile_end': (C.c_int, [_vp, _i64p, _dp, _dp, _dp]),

@@ -57,6 +57,7 @@ struct DevModel {
     double cphi, sphi;     // cos/sin(k2 r_off)
     double cth, sth;       // cos(k2 L), |sin(k2 L)|
     int sth_sign;          // sign bit of sin(k2 L) (0 or 0x80000000)
+    double sth_signed;     // sin(k2 L)
     // short-range variants (pair_core4): angles c_v added to k2 z_own,
     // v = (no wrap, d > 0), (no wrap, d < 0), (D > L/2), (D < -L/2)
     double var_cos[4], var_sin[4];
@@ -71,7 +72,21 @@ struct DevModel {
     double v_barrier;
     double k1_2pi;         // k1 * 2 / pi
     double k1_half;        // k1 / 2
+    // one-body table (one_body_tab): rows of OB_ROW doubles in device memory,
+    // ob_m1 rows over the well [0, z_a], ob_m2 over the barrier [z_a, 1), one
+    // closing row; null when the direct evaluation is used
+    const double *ob_table;
+    int ob_m1, ob_m2;
+    double ob_invh1;       // m1 / z_a
+    double ob_invh2;       // m2 / z_b   (>= ob_invh1)
+    double ob_shift2;      // m1 / ob_invh2 - z_a
 };
+
+// One-body table row (128 bytes, one cache line per particle): degree OB_DEG
+// polynomials in t in [0, 1) across one interval of the unit cell,
+// [0, 8) f1'/f1 and [8, 16) log f1.
+#define OB_DEG 7
+#define OB_ROW 16
 
 // ---------------------------------------------------------------- RNG ----
 // Philox4x32-10 (Salmon et al. 2011), counter = (slot, step, index, stream),
@@ -197,10 +212,17 @@ __device__ __forceinline__ void resort_step(double (&z)[P], int (&lab)[P],
 }
 
 // Per-particle table entry kept in registers by the owner and published to LDS.
-struct PTab {
-    double s, c;    // sin/cos(pi z / L)
-    double su, cu;  // sin/cos(k2 z)
+// R is the arithmetic type of the pair loop: double, or float for the
+// reduced-precision variant (the reference's `jit_fastmath` knob,
+// mrbp_qmc/dmc.py:159-160; never the default).  Positions, the per-particle
+// tables' sin/cos, the one-body factor, the energy assembly and the logarithms
+// stay in double either way.
+template <typename R>
+struct PTabT {
+    R s, c;    // sin/cos(pi z / L)
+    R su, cu;  // sin/cos(k2 z)
 };
+typedef PTabT<double> PTab;
 
 // One-body factor (mrbp_qmc/model.py:404-464) and lattice potential (:533-551).
 // ldz = f1'/f1; kin_pot = -f1''/f1 + ldz^2 + V(z); the factor itself is
@@ -248,26 +270,95 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
     }
 }
 
+// The same from the table.  The one-body factor is a fixed function of the
+// position inside the unit cell: f1'/f1 and log f1 are tabulated per model as
+// piecewise degree-7 polynomials (host: build_ob_table in qmcwalk.hip, which
+// verifies them against the closed forms to ~1e-15 and falls back to the
+// direct evaluation when a model does not reach that).  Both lattice regions
+// cost the same ~25 instructions here; evaluated directly the two transcendental
+// branches run one after the other in nearly every wave (~140).  The rows
+// (<= 64 KB) are read through the vector cache; the loads are issued before
+// pair tables occupy registers.
+// `logf1` is log of the factor itself (the direct path returns the factor and
+// a split-off exponent).
+typedef const __attribute__((address_space(1))) double *qmc_gptr;
+
+template <bool WF>
+__device__ __forceinline__ void one_body_tab(const DevModel &m, double z,
+                                             double &ldz, double &logf1,
+                                             bool &barrier)
+{
+    const double zc = __builtin_amdgcn_fract(z);
+    // the region decides -f1''/f1 + V, which jumps at z_a: an exact compare,
+    // as in the reference (mrbp_qmc/model.py:464, 549), not the row index
+    barrier = m.z_a < zc;
+    // row + position inside it.  The map is piecewise linear (slope m1 / z_a
+    // over the well, m2 / z_b >= that over the barrier, continuous at z_a),
+    // i.e. the larger of its two lines: no compare, no select.  (f1'/f1 and
+    // log f1 are continuous at z_a, so a last-bit difference between this
+    // and the compare above is harmless.)
+    const double u = fmax(zc * m.ob_invh1, (zc + m.ob_shift2) * m.ob_invh2);
+    // 32-bit row offset against the uniform base: global loads with a scalar
+    // base address (a generic pointer would make them flat loads)
+    const unsigned off = (unsigned)(int)u * OB_ROW;
+    const double t = __builtin_amdgcn_fract(u);
+    const qmc_gptr r = (qmc_gptr)m.ob_table + off;
+    double p = r[OB_DEG];
+#pragma unroll
+    for (int k = OB_DEG - 1; k >= 0; --k) p = fma(p, t, r[k]);
+    ldz = p;
+    if (WF) {
+        double q = r[8 + OB_DEG];
+#pragma unroll
+        for (int k = OB_DEG - 1; k >= 0; --k) q = fma(q, t, r[8 + k]);
+        logf1 = q;
+    }
+}
+
+// -f1''/f1 + V(z) of a particle (added to (f1'/f1)^2): e0 in the well,
+// V - (V0 - e0) in a barrier of height V (mrbp_qmc/model.py:446-464, 533-551).
+__device__ __forceinline__ double one_body_kin_const(const DevModel &m,
+                                                     double z, bool barrier)
+{
+    double v = m.v_barrier;
+    if (!m.uniform_barrier) {
+        // lattice defects: every defects_sep-th barrier has height v0d
+        // (floor and a non-negative remainder: callers of the batch
+        // evaluation may pass positions outside [0, L))
+        int rr = (int)floor(z) % m.defects_sep;
+        if (rr < 0) rr += m.defects_sep;
+        v = (rr == 0) ? m.v0d : m.v0;
+    }
+    return barrier ? v - m.v0_minus_e0 : m.e0;
+}
+
 // Constants of the pair loop, loaded once per walker evaluation.  The two that
 // feed a copysign live in VGPRs (a v_bfi on the high dword then needs no move
 // of the low dword from an SGPR every pair).
-struct PairConsts {
-    double sin_rm, cth, m_k2cphi, sphi, cphi;
-    double v_sth, v_k2sphi;       // VGPR-resident
-    double half_L, rm, L_minus_rm;
-    double m_k2;
+template <typename R>
+struct PairConstsT {
+    R sin_rm, cth, m_k2cphi, sphi, cphi;
+    R v_sth, v_k2sphi;       // VGPR-resident
+    R half_L, rm, L_minus_rm;
+    R m_k2;
     int sth_sign;
+    R sth_signed, k2sphi;
+    R k2sq, inv_beta, b_long;
 };
+typedef PairConstsT<double> PairConsts;
 
-__device__ __forceinline__ PairConsts load_pair_consts(const DevModel &m)
+template <typename R>
+__device__ __forceinline__ PairConstsT<R> load_pair_consts(const DevModel &m)
 {
-    PairConsts c;
-    c.sin_rm = m.sin_rm; c.cth = m.cth; c.m_k2cphi = m.m_k2cphi;
-    c.sphi = m.sphi; c.cphi = m.cphi;
-    c.half_L = m.half_L; c.rm = m.rm; c.L_minus_rm = m.L_minus_rm;
-    c.v_sth = m.sth; c.v_k2sphi = m.k2sphi;
+    PairConstsT<R> c;
+    c.sin_rm = (R)m.sin_rm; c.cth = (R)m.cth; c.m_k2cphi = (R)m.m_k2cphi;
+    c.sphi = (R)m.sphi; c.cphi = (R)m.cphi;
+    c.half_L = (R)m.half_L; c.rm = (R)m.rm; c.L_minus_rm = (R)m.L_minus_rm;
+    c.v_sth = (R)m.sth; c.v_k2sphi = (R)m.k2sphi;
     c.sth_sign = m.sth_sign;
-    c.m_k2 = m.m_k2;
+    c.m_k2 = (R)m.m_k2;
+    c.sth_signed = (R)m.sth_signed; c.k2sphi = (R)m.k2sphi;
+    c.k2sq = (R)m.k2sq; c.inv_beta = (R)m.inv_beta; c.b_long = (R)m.b_long;
     asm volatile("" : "+v"(c.v_sth), "+v"(c.v_k2sphi));
     return c;
 }
@@ -278,57 +369,67 @@ __device__ __forceinline__ PairConsts load_pair_consts(const DevModel &m)
 //   Yout    : the denominator = the factor |f2| up to constants
 //             (short: cos(k2 r - phi); long: sin(pi d / L), signed)
 //   isshort : r < rm
-template <bool ZCLASS>
-__device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
-                                          double aks, double akc, double za,
-                                          const PTab &b, double zb, double &q,
-                                          double &Yout, bool &isshort,
+template <bool ZCLASS, typename R>
+__device__ __forceinline__ void pair_core(const PairConstsT<R> &m,
+                                          const PTabT<R> &a, R aks, R akc,
+                                          R za, const PTabT<R> &b, R zb, R &q,
+                                          R &Yout, bool &isshort,
                                           unsigned long long &shortmask)
 {
-    double S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
-    double X = akc * b.c + aks * b.s;     // a_long * cos(...)
-    double Y = S;
+    R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
+    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R Y = S;
     bool wrapped;
     if (ZCLASS) {
-        double aD = fabs(za - zb);
+        R aD = q_abs(za - zb);
         wrapped = aD > m.half_L;
         isshort = (aD < m.rm) | (aD > m.L_minus_rm);
     } else {
-        wrapped = X < 0.0;                // |z_a - z_b| > L/2
-        isshort = fabs(S) < m.sin_rm;     // min-image r < rm
+        wrapped = X < (R)0;               // |z_a - z_b| > L/2
+        isshort = q_abs(S) < m.sin_rm;    // min-image r < rm
     }
     // taken here, in the block of the compare, the ballot is the compare's own
     // SGPR mask (later it costs a v_cndmask + v_cmp round trip)
     shortmask = __ballot(isshort);
     if (isshort) {
-        double Su = a.su * b.cu - a.cu * b.su;   // sin(k2 (z_a - z_b))
-        double Cu = a.cu * b.cu + a.su * b.su;
+        R Su = a.su * b.cu - a.cu * b.su;   // sin(k2 (z_a - z_b))
+        R Cu = a.cu * b.cu + a.su * b.su;
         if (wrapped) {
             // keep this a real (exec-masked) branch: as selects it costs four
             // v_cndmask on top of the arithmetic
             asm volatile("");
             // min image d = D - sgn(D) L; sgn(D) = sgn(S)
-            // t = sin(k2 L) sgn(S): copysign on |sin(k2 L)|, then the sign of
-            // sin(k2 L) itself (k2 L is any angle) xor-ed into the high word
-            double t = __builtin_copysign(m.v_sth, S);
-            t = __hiloint2double(__double2hiint(t) ^ m.sth_sign,
-                                 __double2loint(t));
-            double ct, st;
-            const double cth = m.cth;
-            // in place, exactly four instructions (the compiler's two-address
-            // v_fmac form needs two extra 64-bit moves at the join)
-            asm("v_mul_f64 %[ct], %[cu], %[t]\n\t"
-                "v_mul_f64 %[st], %[su], %[t]\n\t"
-                "v_fma_f64 %[su], %[su], %[cth], -%[ct]\n\t"
-                "v_fma_f64 %[cu], %[cu], %[cth], %[st]"
-                : [su] "+v"(Su), [cu] "+v"(Cu), [ct] "=&v"(ct), [st] "=&v"(st)
-                : [t] "v"(t), [cth] "s"(cth));
+            if constexpr (sizeof(R) == 8) {
+                // t = sin(k2 L) sgn(S): copysign on |sin(k2 L)|, then the sign
+                // of sin(k2 L) itself (k2 L is any angle) xor-ed into the high
+                // word
+                double t = __builtin_copysign(m.v_sth, S);
+                t = __hiloint2double(__double2hiint(t) ^ m.sth_sign,
+                                     __double2loint(t));
+                double ct, st;
+                const double cth = m.cth;
+                // in place, exactly four instructions (the compiler's
+                // two-address v_fmac form needs two extra 64-bit moves at the
+                // join)
+                asm("v_mul_f64 %[ct], %[cu], %[t]\n\t"
+                    "v_mul_f64 %[st], %[su], %[t]\n\t"
+                    "v_fma_f64 %[su], %[su], %[cth], -%[ct]\n\t"
+                    "v_fma_f64 %[cu], %[cu], %[cth], %[st]"
+                    : [su] "+v"(Su), [cu] "+v"(Cu), [ct] "=&v"(ct),
+                      [st] "=&v"(st)
+                    : [t] "v"(t), [cth] "s"(cth));
+            } else {
+                const R t = q_copysign(m.sth_signed, S * m.sth_signed);
+                const R ns = Su * m.cth - Cu * t;
+                const R nc = Cu * m.cth + Su * t;
+                Su = ns; Cu = nc;
+            }
         }
         // now (Su, Cu) = sin/cos(k2 d), |k2 d| < pi/2, sgn(Su) = sgn(d):
         //   -k2 tan(k2 r - phi) sgn(d) = X / Y with
-        double t2 = __builtin_copysign(m.v_k2sphi, Su);
-        X = fma(m.m_k2cphi, Su, Cu * t2);
-        Y = fma(fabs(Su), m.sphi, Cu * m.cphi);
+        R t2 = q_copysign(m.v_k2sphi, Su);
+        X = q_fma(m.m_k2cphi, Su, Cu * t2);
+        Y = q_fma(q_abs(Su), m.sphi, Cu * m.cphi);
     }
     q = pair_div(X, Y);
     Yout = Y;
@@ -344,46 +445,49 @@ __device__ __forceinline__ void pair_core(const PairConsts &m, const PTab &a,
 // and step); a pair is then 4 instructions in the branch of its case instead
 // of the rotate-by-k2 L / copysign sequence.  With position-sorted lanes
 // nearly every lane of a rotation step is in the same one or two cases.
-struct ShortTab {
-    double s[4], c[4];
+template <typename R>
+struct ShortTabT {
+    R s[4], c[4];
 };
+typedef ShortTabT<double> ShortTab;
 
+template <typename R>
 __device__ __forceinline__ void make_short_tab(const DevModel &m, double su,
-                                               double cu, ShortTab &st)
+                                               double cu, ShortTabT<R> &st)
 {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        st.s[v] = fma(su, m.var_cos[v], cu * m.var_sin[v]);
-        st.c[v] = fma(cu, m.var_cos[v], -(su * m.var_sin[v]));
+        st.s[v] = (R)fma(su, m.var_cos[v], cu * m.var_sin[v]);
+        st.c[v] = (R)fma(cu, m.var_cos[v], -(su * m.var_sin[v]));
     }
 }
 
-template <bool ZCLASS>
-__device__ __forceinline__ void pair_core4(const PairConsts &m, const PTab &a,
-                                           const ShortTab &sa, double aks,
-                                           double akc, double za,
-                                           const PTab &b, double zb, double &q,
-                                           double &Yout, bool &isshort,
+template <bool ZCLASS, typename R>
+__device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
+                                           const PTabT<R> &a,
+                                           const ShortTabT<R> &sa, R aks,
+                                           R akc, R za, const PTabT<R> &b,
+                                           R zb, R &q, R &Yout, bool &isshort,
                                            unsigned long long &shortmask)
 {
-    double S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
-    double X = akc * b.c + aks * b.s;     // a_long * cos(...)
-    double Y = S;
+    R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
+    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R Y = S;
     bool wrapped, neg;
     if (ZCLASS) {
-        const double D = za - zb;
-        const double aD = fabs(D);
+        const R D = za - zb;
+        const R aD = q_abs(D);
         wrapped = aD > m.half_L;
-        neg = D < 0.0;
+        neg = D < (R)0;
         isshort = (aD < m.rm) | (aD > m.L_minus_rm);
     } else {
-        wrapped = X < 0.0;                // |z_a - z_b| > L/2
-        neg = S < 0.0;                    // sgn(D) = sgn(sin(pi D / L))
-        isshort = fabs(S) < m.sin_rm;     // min-image r < rm
+        wrapped = X < (R)0;               // |z_a - z_b| > L/2
+        neg = S < (R)0;                   // sgn(D) = sgn(sin(pi D / L))
+        isshort = q_abs(S) < m.sin_rm;    // min-image r < rm
     }
     shortmask = __ballot(isshort);
     if (isshort) {
-        double xs, ys;
+        R xs, ys;
         // real (exec-masked) branches: as selects the four cases would cost
         // eight v_cndmask per double pair
 #define QMC_CASE4(v)                                                          \
@@ -400,6 +504,71 @@ __device__ __forceinline__ void pair_core4(const PairConsts &m, const PTab &a,
 #undef QMC_CASE4
         X = m.m_k2 * xs;
         Y = ys;
+    }
+    q = pair_div(X, Y);
+    Yout = Y;
+}
+
+// Short-range pair, one-case form (P = 1, doubled tables).  The second copy of
+// the LDS tables is what a lane reads when its partner index wraps around the
+// lane group (gl - k < 0).  With position-sorted lanes that partner sits at the
+// far end of the box, one period above: the copy therefore holds the tables of
+// z - L (sin, cos of pi z / L negated; k2 z rotated by -k2 L), so that the
+// pair looks like an ordinary one with 0 < D < L/2.  Then EVERY short-range
+// pair of a sorted walker is the case (no wrap, D > 0) of pair_core4: one
+// four-instruction body for the whole wave (the four-case form runs two
+// bodies in every step, lanes gl >= k in one, lanes gl < k in another), no
+// multiply by -k2 (folded into the own table) and 8 instead of 28 registers
+// of own tables.  Lanes whose pair is not in that case (imperfect order
+// after a move) take the generic path below; it is exact for any order.
+template <typename R>
+struct OwnShort1T {
+    R s0, c0;      // sin, cos(k2 z - phi)
+    R ks0, kc0;    // -k2 times the same
+};
+
+template <typename R>
+__device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
+                                           R ac, const OwnShort1T<R> &o,
+                                           R aks, R akc, const PTabT<R> &b,
+                                           bool lower, R own_su, R own_cu,
+                                           R &q, R &Yout, bool &isshort,
+                                           unsigned long long &shortmask)
+{
+    R S = as * b.c - ac * b.s;       // sin(pi (z_a - z_b') / L)
+    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R Y = S;
+    isshort = q_abs(S) < m.sin_rm;   // min-image r < rm
+    shortmask = __ballot(isshort);
+    if (isshort) {
+        if ((S > (R)0) & (X > (R)0)) {
+            // 0 < D' < L/2: theta = k2 D' - phi, X = -k2 sin, Y = cos
+            asm volatile("");
+            X = o.ks0 * b.cu - o.kc0 * b.su;
+            Y = o.c0 * b.cu + o.s0 * b.su;
+        } else {
+            asm volatile("");
+            // generic (exact for any order of the lanes): undo the copy's
+            // shift by one period, then the sequence of pair_core
+            R bsu = b.su, bcu = b.cu, Sg = S, Xg = X;
+            if (lower) {
+                const R s2 = bsu * m.cth + bcu * m.sth_signed;
+                const R c2 = bcu * m.cth - bsu * m.sth_signed;
+                bsu = s2; bcu = c2; Sg = -S; Xg = -X;
+            }
+            R Su = own_su * bcu - own_cu * bsu;   // sin(k2 (z_a - z_b))
+            R Cu = own_cu * bcu + own_su * bsu;
+            if (Xg < (R)0) {
+                // |D| > L/2: min image d = D - sgn(D) L, sgn(D) = sgn(Sg)
+                const R t = (Sg < (R)0) ? -m.sth_signed : m.sth_signed;
+                const R ns = Su * m.cth - Cu * t;
+                const R nc = Cu * m.cth + Su * t;
+                Su = ns; Cu = nc;
+            }
+            const R t2 = q_copysign(m.k2sphi, Su);
+            X = q_fma(m.m_k2cphi, Su, Cu * t2);
+            Y = q_fma(q_abs(Su), m.sphi, Cu * m.cphi);
+        }
     }
     q = pair_div(X, Y);
     Yout = Y;
@@ -424,7 +593,8 @@ struct GroupLds {
 //   eith[P]   : out if ITH, local energy per particle
 //   E         : out, local energy of the walker (same value in every lane)
 //   logwf     : out if WF, log|psi| (same value in every lane)
-template <int G, int P, bool PAD, bool WF, bool ITH, bool ZCLASS>
+template <int G, int P, bool PAD, bool WF, bool ITH, bool ZCLASS,
+          typename R = double>
 __device__ __forceinline__ void eval_walker(const DevModel &m,
                                             const double (&z)[P], int gl,
                                             double *lds, double (&F)[P],
@@ -438,18 +608,25 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     // two passes of four own particles (tables re-read from LDS).
     constexpr int PA = (P > 4) ? 4 : P;
     constexpr int NPASS = P / PA;
-    double *lS = lds, *lC = lds + ROW, *lSU = lds + 2 * ROW,
-           *lCU = lds + 3 * ROW, *lZ = lds + 4 * ROW;
+    constexpr bool RD = sizeof(R) == 8;      // the pair loop runs in double
+    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW,
+      *lCU = lS + 3 * ROW, *lZ = lS + 4 * ROW;
     const int n = m.n;
+    // one-case form with a shifted second copy of the tables (pair_core1)
+    // (float pair loop only: in double the four-case form below measured
+    // 1.3 % faster, in float this one 2.3 % -- profiles/r02_ab_variants.txt)
+    constexpr bool ROTCOPY = (DUP == 2) && !ZCLASS && !RD;
     // four-case short-range form while the own tables fit (see pair_core4)
-    constexpr bool FOURCASE = (P <= 2);
-    PTab t[PA];
-    ShortTab st4[FOURCASE ? PA : 1];
-    double aks[PA], akc[PA];   // a_long * (sin, cos)(pi z / L)
+    constexpr bool FOURCASE = (P <= 2) && !ROTCOPY;
+    PTabT<R> t[PA];
+    ShortTabT<R> st4[FOURCASE ? PA : 1];
+    OwnShort1T<R> os1[ROTCOPY ? PA : 1];
+    R aks[PA], akc[PA];      // a_long * (sin, cos)(pi z / L)
+    const R a_long_r = (R)m.a_long;
     bool ok[P];
     double kin1[P];          // one-body kinetic + potential (ITH)
     double kin1_sum = 0.0;   // their sum over the own particles (!ITH)
-    double prodS = 1.0, prodL = 1.0;   // running products of pair factors (WF)
+    R prodS = 1, prodL = 1;  // running products of pair factors (WF)
     double prod1 = 1.0;      // product of the one-body factors (WF)
     double xoff_sum = 0.0;   // sum of the exponents split off them (one_body)
     int expS = 0, expL = 0;  // binary exponents split off the products
@@ -459,38 +636,42 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     // ballot + scalar popcount (SALU) instead of a per-lane VALU add
     constexpr bool WAVE_COUNT = (G == 64) && !PAD;
     int ns_wave = 0;
-    double Qall = 0.0, Qs = 0.0;  // sum of q^2 over all / short pairs
-    double Kown[P], KT[P];   // per-particle pair kinetic sums (ITH)
-    double T[P];             // travelling drift of the partner lane
+    int nb_wave = 0;         // particles inside a barrier (one-body table path)
+    bool nb_counted = false;
+    R Qall = 0, Qs = 0;      // sum of q^2 over all / short pairs
+    R Kown[P], KT[P];        // per-particle pair kinetic sums (ITH)
+    R T[P];                  // travelling drift of the partner lane
+    R Fr[P];                 // drift sums of the pair loop
 
     QMC_SECTION("tables+onebody");
 #pragma unroll
     for (int a = 0; a < P; ++a) {
         ok[a] = !PAD || (gl + G * a) < n;
-        F[a] = 0.0; T[a] = 0.0; Kown[a] = 0.0; KT[a] = 0.0;
+        F[a] = 0.0; T[a] = 0; Kown[a] = 0; KT[a] = 0;
         if (ITH) kin1[a] = 0.0;
-        if (!m.is_ideal) {
-            PTab ta;
-            sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
-            sincos_halfpi(z[a] * m.k2_2pi, ta.su, ta.cu);
-            if (NPASS == 1) {
-                t[a % PA] = ta;
-                aks[a % PA] = m.a_long * ta.s;
-                akc[a % PA] = m.a_long * ta.c;
-                if (FOURCASE) make_short_tab(m, ta.su, ta.cu, st4[a % PA]);
+        // the one-body factor first: its table rows (or its transcendental
+        // branches) are done with before the pair tables occupy registers
+        if (!m.is_free && m.ob_table) {
+            double ldz, lf = 0.0;
+            bool barrier;
+            one_body_tab<WF>(m, z[a], ldz, lf, barrier);
+            if (WAVE_COUNT && !ITH && m.uniform_barrier) {
+                // one walker per wavefront, every barrier alike: the region
+                // constants are counted on the scalar unit and added once
+                nb_wave += __popcll(__ballot(barrier));
+                nb_counted = true;
+                F[a] = ldz;
+                kin1_sum = fma(ldz, ldz, kin1_sum);
+                if (WF) xoff_sum -= lf;
+            } else if (ok[a]) {
+                const double kp =
+                    fma(ldz, ldz, one_body_kin_const(m, z[a], barrier));
+                F[a] = ldz;
+                if (ITH) kin1[a] = kp; else kin1_sum += kp;
+                // log f1 joins the sum of split-off exponents (subtracted)
+                if (WF) xoff_sum -= lf;
             }
-            int i0 = a * DUP * G + gl;
-            lS[i0] = ta.s; lC[i0] = ta.c; lSU[i0] = ta.su; lCU[i0] = ta.cu;
-            if (ZCLASS) lZ[i0] = z[a];
-            if (DUP == 2) {
-                lS[i0 + G] = ta.s; lC[i0 + G] = ta.c;
-                lSU[i0 + G] = ta.su; lCU[i0 + G] = ta.cu;
-                if (ZCLASS) lZ[i0 + G] = z[a];
-            }
-        } else if (NPASS == 1) {
-            aks[a % PA] = 0.0; akc[a % PA] = 0.0;
-        }
-        if (!m.is_free) {
+        } else if (!m.is_free) {
             double ldz, kp, f1, xoff;
             one_body(m, z[a], ldz, kp, f1, xoff);
             if (ok[a]) {
@@ -506,15 +687,55 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 }
             }
         }
+        // (in double the pair sums continue from the one-body term, as ever)
+        Fr[a] = RD ? (R)F[a] : (R)0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!m.is_ideal) {
+            PTab ta;
+            sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
+            sincos_halfpi(z[a] * m.k2_2pi, ta.su, ta.cu);
+            if (NPASS == 1) {
+                t[a % PA].s = (R)ta.s; t[a % PA].c = (R)ta.c;
+                t[a % PA].su = (R)ta.su; t[a % PA].cu = (R)ta.cu;
+                aks[a % PA] = (R)(m.a_long * ta.s);
+                akc[a % PA] = (R)(m.a_long * ta.c);
+                if (FOURCASE) make_short_tab<R>(m, ta.su, ta.cu, st4[a % PA]);
+                if (ROTCOPY) {
+                    OwnShort1T<R> &o = os1[a % PA];
+                    const double s0 = fma(ta.su, m.cphi, -(ta.cu * m.sphi));
+                    const double c0 = fma(ta.cu, m.cphi, ta.su * m.sphi);
+                    o.s0 = (R)s0; o.c0 = (R)c0;
+                    o.ks0 = (R)(m.m_k2 * s0);
+                    o.kc0 = (R)(m.m_k2 * c0);
+                }
+            }
+            int i0 = a * DUP * G + gl;
+            if (ROTCOPY) {
+                // upper copy: the particle itself; lower copy (read when the
+                // partner index wraps): the particle one period below
+                lS[i0 + G] = (R)ta.s; lC[i0 + G] = (R)ta.c;
+                lSU[i0 + G] = (R)ta.su; lCU[i0 + G] = (R)ta.cu;
+                lS[i0] = (R)-ta.s; lC[i0] = (R)-ta.c;
+                lSU[i0] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
+                lCU[i0] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
+            } else {
+                lS[i0] = (R)ta.s; lC[i0] = (R)ta.c;
+                lSU[i0] = (R)ta.su; lCU[i0] = (R)ta.cu;
+                if (ZCLASS) lZ[i0] = (R)z[a];
+                if (DUP == 2) {
+                    lS[i0 + G] = (R)ta.s; lC[i0 + G] = (R)ta.c;
+                    lSU[i0 + G] = (R)ta.su; lCU[i0 + G] = (R)ta.cu;
+                    if (ZCLASS) lZ[i0 + G] = (R)z[a];
+                }
+            }
+        } else if (NPASS == 1) {
+            aks[a % PA] = 0; akc[a % PA] = 0;
+        }
     }
 
     // Split the binary exponent off a running product so that it can neither
     // underflow nor overflow (one frexp pair instead of a log per fold).
-#define QMC_FOLD(p, e)                                                        \
-    do {                                                                      \
-        e += __builtin_amdgcn_frexp_exp(p);                                   \
-        p = __builtin_amdgcn_frexp_mant(p);                                   \
-    } while (0)
+#define QMC_FOLD(p, e) q_fold(p, e)
     // own table of particle (lane gl, register a) back from LDS
 #define QMC_LOAD_OWN(dst, a)                                                  \
     do {                                                                      \
@@ -524,7 +745,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     } while (0)
 
     if (!m.is_ideal) {
-        const PairConsts pc = load_pair_consts(m);
+        const PairConstsT<R> pc = load_pair_consts<R>(m);
         // make the table visible to the other lanes of the wave (one wave owns
         // its groups' LDS region: LDS ops of a wave complete in order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -534,51 +755,52 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // sums that count every unordered pair once
 #define QMC_TALLY(q, Y, isshort)                                              \
     do {                                                                      \
-        Qall = fma(q, q, Qall);                                               \
+        Qall = q_fma(q, q, Qall);                                             \
         if (!WAVE_COUNT) ++npair;                                             \
         /* prodL runs over ALL pairs (no else branch, no second compare);   \
            the short factors are divided out once at the end */             \
         if (WF) prodL *= Y;          /* sign dropped at the end */            \
         if (isshort) {                                                        \
             asm volatile("");   /* exec-masked, not selects */                \
-            Qs = fma(q, q, Qs);                                               \
+            Qs = q_fma(q, q, Qs);                                             \
             if (!WAVE_COUNT) ++nshort;                                        \
             if (WF) prodS *= Y;                                               \
         }                                                                     \
     } while (0)
 #define QMC_PAIR_KIN(q, isshort)                                              \
-    ((isshort) ? fma(q, q, m.k2sq) : fma((q) * (q), m.inv_beta, m.b_long))
+    ((isshort) ? q_fma(q, q, pc.k2sq)                                         \
+               : q_fma((q) * (q), pc.inv_beta, pc.b_long))
 
         // ---- k = 0: pairs inside the lane ----
         QMC_SECTION("pairs_in_lane");
 #pragma unroll
         for (int a = 0; a < P; ++a) {
-            PTab ta; double aksa, akca;
+            PTabT<R> ta; R aksa, akca;
             if (NPASS == 1) {
                 ta = t[a % PA]; aksa = aks[a % PA]; akca = akc[a % PA];
             } else if (a + 1 < P) {
                 QMC_LOAD_OWN(ta, a);
-                aksa = m.a_long * ta.s; akca = m.a_long * ta.c;
+                aksa = a_long_r * ta.s; akca = a_long_r * ta.c;
             }
 #pragma unroll
             for (int b = a + 1; b < P; ++b) {
-                PTab tb;
+                PTabT<R> tb;
                 if (NPASS == 1) tb = t[b % PA];
                 else QMC_LOAD_OWN(tb, b);
-                double q, Y; bool sh; unsigned long long shm;
+                R q, Y; bool sh; unsigned long long shm;
                 if (FOURCASE)
-                    pair_core4<ZCLASS>(pc, ta, st4[a % PA], aksa, akca, z[a],
-                                       tb, z[b], q, Y, sh, shm);
+                    pair_core4<ZCLASS, R>(pc, ta, st4[a % PA], aksa, akca,
+                                          (R)z[a], tb, (R)z[b], q, Y, sh, shm);
                 else
-                    pair_core<ZCLASS>(pc, ta, aksa, akca, z[a], tb, z[b], q,
-                                      Y, sh, shm);
+                    pair_core<ZCLASS, R>(pc, ta, aksa, akca, (R)z[a], tb,
+                                         (R)z[b], q, Y, sh, shm);
                 if (WAVE_COUNT)
                     ns_wave += __popcll(shm);
                 if (!PAD || (ok[a] && ok[b])) {
-                    F[a] += q; F[b] -= q;
+                    Fr[a] += q; Fr[b] -= q;
                     QMC_TALLY(q, Y, sh);
                     if (ITH) {
-                        double kk = QMC_PAIR_KIN(q, sh);
+                        R kk = QMC_PAIR_KIN(q, sh);
                         Kown[a] += kk; Kown[b] += kk;
                     }
                 }
@@ -599,36 +821,44 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             /* partner-major order: one partner table live at a time */       \
             _Pragma("unroll")                                                 \
             for (int b = 0; b < P; ++b) {                                     \
-                PTab pb;                                                      \
+                PTabT<R> pb;                                                  \
                 const int idx = (DUP == 2) ? b * 2 * G + gl + G - (k)         \
                                            : b * G + ((gl - (k)) & (G - 1));  \
                 pb.s = lS[idx]; pb.c = lC[idx];                               \
                 pb.su = lSU[idx]; pb.cu = lCU[idx];                           \
-                const double pz = ZCLASS ? lZ[idx] : 0.0;                     \
+                const R pz = ZCLASS ? lZ[idx] : (R)0;                         \
                 int pl = gl - (k); if (pl < 0) pl += G;                       \
                 const bool pok = !PAD || (pl + G * b) < n;                    \
                 _Pragma("unroll")                                             \
                 for (int a = 0; a < PA; ++a) {                                \
                     constexpr int ao_base = (H) * PA;                         \
-                    double q, Y; bool sh; unsigned long long shm;            \
-                    if (FOURCASE)                                             \
-                        pair_core4<ZCLASS>(pc, t[a], st4[FOURCASE ? a : 0],   \
-                                           aks[a], akc[a], z[ao_base + a],    \
-                                           pb, pz, q, Y, sh, shm);            \
+                    R q, Y; bool sh; unsigned long long shm;                 \
+                    if (ROTCOPY)                                              \
+                        pair_core1<R>(pc, t[a].s, t[a].c,                     \
+                                      os1[ROTCOPY ? a : 0], aks[a], akc[a],   \
+                                      pb, gl < (k),                           \
+                                      lSU[a * DUP * G + G + gl],              \
+                                      lCU[a * DUP * G + G + gl], q, Y, sh,    \
+                                      shm);                                   \
+                    else if (FOURCASE)                                        \
+                        pair_core4<ZCLASS, R>(pc, t[a],                       \
+                                              st4[FOURCASE ? a : 0], aks[a],  \
+                                              akc[a], (R)z[ao_base + a], pb,  \
+                                              pz, q, Y, sh, shm);             \
                     else                                                      \
-                        pair_core<ZCLASS>(pc, t[a], aks[a], akc[a],           \
-                                          z[ao_base + a], pb, pz, q, Y, sh,   \
-                                          shm);                               \
+                        pair_core<ZCLASS, R>(pc, t[a], aks[a], akc[a],        \
+                                             (R)z[ao_base + a], pb, pz, q, Y, \
+                                             sh, shm);                        \
                     /* G = 64: the lower half of the lanes is bits 0..31 */   \
                     if (WAVE_COUNT)                                           \
                         ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \
                                                    : shm);                    \
                     if (!PAD || (ok[ao_base + a] && pok)) {                   \
-                        F[ao_base + a] += q;                                  \
+                        Fr[ao_base + a] += q;                                 \
                         if (!(LAST)) T[b] -= q;                               \
                         if (!(LAST) || count_pair) { QMC_TALLY(q, Y, sh); }   \
                         if (ITH) {                                            \
-                            double kk = QMC_PAIR_KIN(q, sh);                  \
+                            R kk = QMC_PAIR_KIN(q, sh);                       \
                             Kown[ao_base + a] += kk;                          \
                             if (!(LAST)) KT[b] += kk;                         \
                         }                                                     \
@@ -659,8 +889,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 _Pragma("unroll")                                             \
                 for (int a = 0; a < PA; ++a) {                                \
                     QMC_LOAD_OWN(t[a], (H) * PA + a);                         \
-                    aks[a] = m.a_long * t[a].s;                               \
-                    akc[a] = m.a_long * t[a].c;                               \
+                    aks[a] = a_long_r * t[a].s;                               \
+                    akc[a] = a_long_r * t[a].c;                               \
                 }                                                             \
             }                                                                 \
             /* (kept rolled: unrolled, the scheduler hoists the LDS reads of \
@@ -674,11 +904,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                holds them) and start the next pass from zero */              \
             _Pragma("unroll")                                                 \
             for (int b = 0; b < P; ++b) {                                     \
-                F[b] += __shfl_xor(T[b], G / 2, 64);                          \
-                T[b] = 0.0;                                                   \
+                Fr[b] += __shfl_xor(T[b], G / 2, 64);                         \
+                T[b] = 0;                                                     \
                 if (ITH) {                                                    \
                     Kown[b] += __shfl_xor(KT[b], G / 2, 64);                  \
-                    KT[b] = 0.0;                                              \
+                    KT[b] = 0;                                                \
                 }                                                             \
             }                                                                 \
         }
@@ -687,6 +917,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 #undef QMC_PASS
 #undef QMC_KSTEP
     }
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+        F[a] = RD ? (double)Fr[a] : F[a] + (double)Fr[a];
 
     // ---- local energy ----
     QMC_SECTION("energy+logwf");
@@ -694,7 +927,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     if (ITH) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
-            double e = ok[a] ? (Kown[a] + kin1[a] - F[a] * F[a]) : 0.0;
+            double e = ok[a] ? ((double)Kown[a] + kin1[a] - F[a] * F[a]) : 0.0;
             eith[a] = e;
             e_lane += e;
         }
@@ -702,7 +935,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // sum over unordered pairs of (k2^2 + q^2) [short] and
         // (b_long + q^2 / beta) [long], counted for both partners
         int nlong = npair - nshort;
-        double pk = Qs + (Qall - Qs) * m.inv_beta;
+        const double Qall_d = (double)Qall, Qs_d = (double)Qs;
+        double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
         if (!WAVE_COUNT)
             pk += m.k2sq * (double)nshort + m.b_long * (double)nlong;
         e_lane = 2.0 * pk;
@@ -712,6 +946,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             if (ok[a]) e_lane -= F[a] * F[a];
     }
     E = group_sum<G>(e_lane);
+    if (WAVE_COUNT && !ITH && nb_counted) {
+        // one-body region constants of the n particles, nb_wave in a barrier
+        E += (double)(n - nb_wave) * m.e0 +
+             (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
+    }
     if (WAVE_COUNT && !ITH && !m.is_ideal) {
         int nl_wave = n * (n - 1) / 2 - ns_wave;
         E += 2.0 * (m.k2sq * (double)ns_wave + m.b_long * (double)nl_wave);
@@ -720,8 +959,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         const double LN2 = 0.693147180559945309417;
         // prodL holds every pair's |Y|, prodS the short ones (cos > 0):
         // long product = prodL / prodS (mantissas; exponents kept apart)
-        double lw = log_pos(prod1 * prodS) +
-                    m.beta * log_pos(fabs(fast_div(prodL, prodS))) +
+        const double prodS_d = (double)prodS, prodL_d = (double)prodL;
+        double lw = log_pos(prod1 * prodS_d) +
+                    m.beta * log_pos(fabs(fast_div(prodL_d, prodS_d))) +
                     LN2 * ((double)(expS + exp1) +
                            m.beta * (double)(expL - expS)) -
                     xoff_sum;

@@ -8,6 +8,11 @@
 
 static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 
+// odd-even transposition passes (resort_step) run every this many steps
+#ifndef QMC_RESORT_EVERY
+#define QMC_RESORT_EVERY 4
+#endif
+
 // --------------------------------------------------------------- kernels ---
 struct EvalArgs {
     const double *pos;   // [W][N]
@@ -16,7 +21,7 @@ struct EvalArgs {
     long long nconf;
 };
 
-template <int G, int P, bool PAD, bool ZC>
+template <int G, int P, bool PAD, bool ZC, typename R = double>
 __global__ void __launch_bounds__(BLOCK)
 evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
 {
@@ -36,7 +41,7 @@ evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
         int i = gl + G * p;
         z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
     }
-    eval_walker<G, P, PAD, true, true, ZC>(m, z, gl, lds, F, ei, E, wf);
+    eval_walker<G, P, PAD, true, true, ZC, R>(m, z, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -60,7 +65,7 @@ struct PrepArgs {
     long long nconf;
 };
 
-template <int G, int P, bool PAD, bool ZC>
+template <int G, int P, bool PAD, bool ZC, typename R = double>
 __global__ void __launch_bounds__(BLOCK)
 prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
 {
@@ -80,7 +85,7 @@ prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
         int i = gl + G * p;
         z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
     }
-    eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, E, wf);
+    eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -122,7 +127,7 @@ struct VmcArgs {
 // LEAN = the production path (Philox uniform proposal, per-chain block sums
 // only); the full variant adds the test-only tape replay, the Gaussian
 // proposal and the per-step series.
-template <int G, int P, bool PAD, bool ZC, bool LEAN>
+template <int G, int P, bool PAD, bool ZC, bool LEAN, typename R = double>
 __global__ void __launch_bounds__(BLOCK)
 vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 {
@@ -175,10 +180,14 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
         zn[p] = forced ? zp : wrap_box(zp + d, m.L);
     }
     QMC_SECTION("resort");
-    if (!forced) resort_step<G, P>(zn, labn, gl, a.step, n, m.L, m.half_L);
+    // (one odd-even pass every QMC_RESORT_EVERY steps keeps the lanes sorted
+    // well enough: a particle moves a few per cent of the spacing per step)
+    if (!forced && (a.step % QMC_RESORT_EVERY) == 0)
+        resort_step<G, P>(zn, labn, gl, a.step / QMC_RESORT_EVERY, n, m.L,
+                          m.half_L);
     double F[P], ei[P], e_new, wf_new;
-    eval_walker<G, P, PAD, true, false, ZC>(m, zn, gl, lds, F, ei, e_new,
-                                            wf_new);
+    eval_walker<G, P, PAD, true, false, ZC, R>(m, zn, gl, lds, F, ei, e_new,
+                                               wf_new);
     QMC_SECTION("metropolis+store");
     if (!forced) {
         if (!LEAN && a.tape) {
@@ -289,7 +298,7 @@ struct EvolveArgs {
 
 // Drift-diffusion + local energy of every child walker
 // (qmc_base/jastrow/dmc.py:758-825, 892-942).
-template <int G, int P, bool PAD, bool ZC>
+template <int G, int P, bool PAD, bool ZC, typename R = double>
 __global__ void __launch_bounds__(BLOCK)
 dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
 {
@@ -347,7 +356,9 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         }
         z[p] = zz;
     }
-    resort_step<G, P>(z, lab, gl, step, n, m.L, m.half_L);
+    if ((step % QMC_RESORT_EVERY) == 0)
+        resort_step<G, P>(z, lab, gl, step / QMC_RESORT_EVERY, n, m.L,
+                          m.half_L);
     // positions and labels leave now: not live across the pair sum
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -358,7 +369,8 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         }
     }
     double F[P], ei[P], e_next, wf;
-    eval_walker<G, P, PAD, false, false, ZC>(m, z, gl, lds, F, ei, e_next, wf);
+    eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei, e_next,
+                                                wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {

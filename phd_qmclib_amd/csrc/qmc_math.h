@@ -13,6 +13,19 @@
 
 #include <hip/hip_runtime.h>
 
+// A polynomial coefficient pinned to a scalar register pair.  v_fma_f64 takes
+// one SGPR operand, so a Horner step fma(p, z, C) is ONE vector instruction
+// when C sits in SGPRs (two s_mov_b32 on the scalar unit).  Left alone the
+// compiler, inside divergent or conditionally executed regions, materialises
+// each constant with two v_mov_b32 to use the two-address v_fmac form: three
+// vector instructions per step (measured: 18-24 extra per log / exp / sincos
+// evaluation, tools/isa_one.sh).
+__device__ __forceinline__ double sconst(double c)
+{
+    asm("" : "+s"(c));
+    return c;
+}
+
 // q = x / y for normal, finite operands: hardware reciprocal estimate
 // (v_rcp_f64, ~2^-25 relative error), one Newton step on the reciprocal, one
 // correction of the quotient.  6 instructions against the 11 of the IEEE
@@ -37,6 +50,44 @@ __device__ __forceinline__ double pair_div(double x, double y)
     return fma(rem, r, q);
 }
 
+// float flavour of the pair quotient (reduced-precision pair loop): the
+// hardware reciprocal is good to 1 ulp, which is what a float carries
+__device__ __forceinline__ float pair_div(float x, float y)
+{
+    return x * __builtin_amdgcn_rcpf(y);
+}
+
+// type-generic helpers of the pair loop (double / float)
+__device__ __forceinline__ double q_abs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float q_abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double q_fma(double a, double b, double c)
+{
+    return __builtin_fma(a, b, c);
+}
+__device__ __forceinline__ float q_fma(float a, float b, float c)
+{
+    return __builtin_fmaf(a, b, c);
+}
+__device__ __forceinline__ double q_copysign(double m, double s)
+{
+    return __builtin_copysign(m, s);
+}
+__device__ __forceinline__ float q_copysign(float m, float s)
+{
+    return __builtin_copysignf(m, s);
+}
+// split the binary exponent off a running product (no underflow, no overflow)
+__device__ __forceinline__ void q_fold(double &p, int &e)
+{
+    e += __builtin_amdgcn_frexp_exp(p);
+    p = __builtin_amdgcn_frexp_mant(p);
+}
+__device__ __forceinline__ void q_fold(float &p, int &e)
+{
+    e += __builtin_amdgcn_frexp_expf(p);
+    p = __builtin_amdgcn_frexp_mantf(p);
+}
+
 __device__ __forceinline__ double fast_rcp(double y)
 {
     double r = __builtin_amdgcn_rcp(y);
@@ -57,9 +108,13 @@ __device__ __forceinline__ void sincos_kernel(double x, double &s, double &c)
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double z = x * x;
-    double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    double ps = fma(z, fma(z, fma(z, fma(z, fma(z, sconst(S6), sconst(S5)),
+                                         sconst(S4)), sconst(S3)), sconst(S2)),
+                    sconst(S1));
     s = fma(x * z, ps, x);
-    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, sconst(C6), sconst(C5)),
+                                         sconst(C4)), sconst(C3)), sconst(C2)),
+                    sconst(C1));
     c = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 
@@ -93,15 +148,15 @@ __device__ __forceinline__ double exp_bounded(double x)
     r = fma(-n, LN2_LO, r);
     // exp(r) = sum r^k / k!, k <= 12: remainder (ln2/2)^13/13! ~ 1.7e-16
     double p = 2.08767569878680989792e-09;            // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);        // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);        // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);        // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);        // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);        // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);        // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);        // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);        // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);        // 1/3!
+    p = fma(p, r, sconst(2.50521083854417187751e-08));        // 1/11!
+    p = fma(p, r, sconst(2.75573192239858906526e-07));        // 1/10!
+    p = fma(p, r, sconst(2.75573192239858906526e-06));        // 1/9!
+    p = fma(p, r, sconst(2.48015873015873015873e-05));        // 1/8!
+    p = fma(p, r, sconst(1.98412698412698412698e-04));        // 1/7!
+    p = fma(p, r, sconst(1.38888888888888888889e-03));        // 1/6!
+    p = fma(p, r, sconst(8.33333333333333333333e-03));        // 1/5!
+    p = fma(p, r, sconst(4.16666666666666666667e-02));        // 1/4!
+    p = fma(p, r, sconst(1.66666666666666666667e-01));        // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -119,16 +174,16 @@ __device__ __forceinline__ double log_pos(double x)
     if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
     double s = fast_div(m - 1.0, m + 1.0);
     double z = s * s;
-    double p = 1.0 / 21.0;
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
+    double p = sconst(1.0 / 21.0);
+    p = fma(p, z, sconst(1.0 / 19.0));
+    p = fma(p, z, sconst(1.0 / 17.0));
+    p = fma(p, z, sconst(1.0 / 15.0));
+    p = fma(p, z, sconst(1.0 / 13.0));
+    p = fma(p, z, sconst(1.0 / 11.0));
+    p = fma(p, z, sconst(1.0 / 9.0));
+    p = fma(p, z, sconst(1.0 / 7.0));
+    p = fma(p, z, sconst(1.0 / 5.0));
+    p = fma(p, z, sconst(1.0 / 3.0));
     double lm = fma(s * z, 2.0 * p, 2.0 * s);
     double de = (double)e;
     return fma(de, LN2_HI, fma(de, LN2_LO, lm));

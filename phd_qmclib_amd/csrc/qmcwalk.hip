@@ -50,9 +50,11 @@ struct qmc_engine {
     bool own_stream = false;
     DevModel dm;
     DevModel *dm_dev = nullptr;
+    double *ob_table_dev = nullptr;     // one-body table rows (or null)
     qmc_model_params mp;
     int G = 64, P = 1;
     bool pad = false;
+    bool fast = false;      // reduced-precision pair loop (float), off by default
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // kernel profile (qmc_engine_profile_begin/end): one event pair around
     // every launch of the dominant kernel (vmc_step / dmc_evolve)
@@ -164,6 +166,11 @@ static unsigned grid_for(long long nwalkers)
     return (unsigned)((nwalkers + gpb - 1) / gpb);
 }
 
+// The float pair loop exists for the one-wavefront-per-walker shapes with
+// pairs classified from the sines (qmc_inst.h).
+template <int G, bool ZC>
+static constexpr bool has_fast() { return G == 64 && !ZC; }
+
 template <int G, int P, bool PAD, bool ZC>
 struct LaunchEval {
     static constexpr bool want_mask(int np) { return np >= 4; }
@@ -171,6 +178,16 @@ struct LaunchEval {
     {
         if (a.nconf <= 0) return 0;
         const size_t lds = lds_bytes<G, P, ZC>();
+        if constexpr (has_fast<G, ZC>()) {
+            if (e->fast) {
+                allow_lds(evaluate_kernel<G, P, PAD, ZC, float>, lds);
+                hipLaunchKernelGGL((evaluate_kernel<G, P, PAD, ZC, float>),
+                                   dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                                   lds, e->stream, e->dm_dev, a);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
         allow_lds(evaluate_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((evaluate_kernel<G, P, PAD, ZC>),
                            dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
@@ -187,6 +204,16 @@ struct LaunchPrep {
     {
         if (a.nconf <= 0) return 0;
         const size_t lds = lds_bytes<G, P, ZC>();
+        if constexpr (has_fast<G, ZC>()) {
+            if (e->fast) {
+                allow_lds(prepare_kernel<G, P, PAD, ZC, float>, lds);
+                hipLaunchKernelGGL((prepare_kernel<G, P, PAD, ZC, float>),
+                                   dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                                   lds, e->stream, e->dm_dev, a);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
         allow_lds(prepare_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((prepare_kernel<G, P, PAD, ZC>),
                            dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
@@ -205,6 +232,26 @@ struct LaunchVmc {
         const bool lean = !a.tape && !a.gaussian && !a.ser_wf && !a.ser_e &&
                           !a.ser_stat && !a.ser_pos;
         ProfScope prof(e);
+        if constexpr (has_fast<G, ZC>()) {
+            if (e->fast) {
+                if (lean) {
+                    allow_lds(vmc_step_kernel<G, P, PAD, ZC, true, float>, lds);
+                    hipLaunchKernelGGL(
+                        (vmc_step_kernel<G, P, PAD, ZC, true, float>),
+                        dim3(grid_for<G>(a.W)), dim3(BLOCK), lds, e->stream,
+                        e->dm_dev, a);
+                } else {
+                    allow_lds(vmc_step_kernel<G, P, PAD, ZC, false, float>,
+                              lds);
+                    hipLaunchKernelGGL(
+                        (vmc_step_kernel<G, P, PAD, ZC, false, float>),
+                        dim3(grid_for<G>(a.W)), dim3(BLOCK), lds, e->stream,
+                        e->dm_dev, a);
+                }
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
         if (lean) {
             allow_lds(vmc_step_kernel<G, P, PAD, ZC, true>, lds);
             hipLaunchKernelGGL((vmc_step_kernel<G, P, PAD, ZC, true>),
@@ -229,8 +276,18 @@ struct LaunchEvolve {
     static int run(const qmc_engine *e, const EvolveArgs &a)
     {
         const size_t lds = lds_bytes<G, P, ZC>();
-        allow_lds(dmc_evolve_kernel<G, P, PAD, ZC>, lds);
         ProfScope prof(e);
+        if constexpr (has_fast<G, ZC>()) {
+            if (e->fast) {
+                allow_lds(dmc_evolve_kernel<G, P, PAD, ZC, float>, lds);
+                hipLaunchKernelGGL((dmc_evolve_kernel<G, P, PAD, ZC, float>),
+                                   dim3(grid_for<G>(a.maxw)), dim3(BLOCK),
+                                   lds, e->stream, e->dm_dev, a);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
+        allow_lds(dmc_evolve_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((dmc_evolve_kernel<G, P, PAD, ZC>),
                            dim3(grid_for<G>(a.maxw)), dim3(BLOCK),
                            lds, e->stream, e->dm_dev, a);
@@ -264,6 +321,7 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.cth = cos(th);
     d.sth = fabs(sin(th));
     d.sth_sign = sin(th) < 0.0 ? (int)0x80000000u : 0;
+    d.sth_signed = sin(th);
     {
         // angles added to k2 z_own for the four short-range cases
         const double ang[4] = { -phi, phi, phi - th, th - phi };
@@ -300,6 +358,161 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     } else {
         d.cf = 1.0;
     }
+}
+
+// ---- one-body table (qmc_device.h one_body_tab) ---------------------------
+// Closed forms of mrbp_qmc/model.py:404-464 in long double.
+static void ob_exact(const DevModel &d, long double zc, bool barrier,
+                     long double &ldz, long double &logf)
+{
+    if (barrier) {
+        const long double x = (long double)d.kp1 *
+                              (zc - 1.0L + 0.5L * (long double)d.z_b);
+        ldz = (long double)d.kp1 * tanhl(x);
+        logf = logl(coshl(x));
+    } else {
+        const long double x = (long double)d.k1 *
+                              (zc - 0.5L * (long double)d.z_a);
+        ldz = -(long double)d.k1 * tanl(x);
+        logf = logl((long double)d.cf * cosl(x));
+    }
+}
+
+// Degree-DEG interpolant of f on [a, a + h] at Chebyshev nodes, as monomial
+// coefficients in t = (x - a) / h (long double elimination, partial pivoting).
+template <int DEG, typename F>
+static void ob_fit(F f, long double a, long double h, double *coef)
+{
+    constexpr int K = DEG + 1;
+    long double A[K][K + 1];
+    for (int j = 0; j < K; ++j) {
+        const long double t = 0.5L * (1.0L + cosl(3.14159265358979323846264338L *
+                                                  (2 * j + 1) / (2.0L * K)));
+        long double pw = 1.0L;
+        for (int k = 0; k < K; ++k) { A[j][k] = pw; pw *= t; }
+        A[j][K] = f(a + h * t);
+    }
+    for (int c = 0; c < K; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < K; ++r)
+            if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+        for (int k = 0; k <= K; ++k) std::swap(A[c][k], A[piv][k]);
+        for (int r = c + 1; r < K; ++r) {
+            const long double g = A[r][c] / A[c][c];
+            for (int k = c; k <= K; ++k) A[r][k] -= g * A[c][k];
+        }
+    }
+    for (int r = K - 1; r >= 0; --r) {
+        long double v = A[r][K];
+        for (int k = r + 1; k < K; ++k) v -= A[r][k] * (long double)coef[k];
+        coef[r] = (double)(v / A[r][r]);
+    }
+}
+
+static double ob_horner(const double *c, int deg, double t)
+{
+    double p = c[deg];
+    for (int k = deg - 1; k >= 0; --k) p = fma(p, t, c[k]);
+    return p;
+}
+
+// Rows of one lattice region at `m` intervals; -> worst error of the double
+// Horner evaluation against the closed forms, relative to max(1, |f|).
+static double ob_build_region(const DevModel &d, bool barrier, int m,
+                              double *rows)
+{
+    const long double lo = barrier ? (long double)d.z_a : 0.0L;
+    const long double len = barrier ? 1.0L - (long double)d.z_a
+                                    : (long double)d.z_a;
+    const long double h = len / m;
+    double worst = 0.0;
+    for (int i = 0; i < m; ++i) {
+        const long double a = lo + h * i;
+        double *r = rows + (size_t)i * OB_ROW;
+        ob_fit<OB_DEG>([&](long double x) {
+            long double l, g; ob_exact(d, x, barrier, l, g); return l; },
+            a, h, r);
+        ob_fit<OB_DEG>([&](long double x) {
+            long double l, g; ob_exact(d, x, barrier, l, g); return g; },
+            a, h, r + 8);
+        for (int q = 0; q <= 12; ++q) {
+            const double t = q / 12.0;
+            long double l, g;
+            ob_exact(d, a + h * (long double)t, barrier, l, g);
+            const double e1 = fabs(ob_horner(r, OB_DEG, t) - (double)l) /
+                              fmax(1.0, fabs((double)l));
+            const double e2 = fabs(ob_horner(r + 8, OB_DEG, t) - (double)g) /
+                              fmax(1.0, fabs((double)g));
+            worst = fmax(worst, fmax(e1, e2));
+        }
+    }
+    return worst;
+}
+
+static double g_ob_last_err[2] = { 0.0, 0.0 };   // diagnostics (info call)
+static constexpr double OB_TOL = 2e-15;
+static constexpr int OB_MAX_ROWS = 1024;        // per region (128 KB)
+
+// -> host table (empty when the model does not reach OB_TOL: the kernels then
+// evaluate the closed forms directly) and the interval counts.
+static void build_ob_table(const DevModel &d, std::vector<double> &tab,
+                           int &m1, int &m2)
+{
+    tab.clear();
+    m1 = m2 = 0;
+    if (d.is_free) return;
+    if (const char *env = getenv("QMCWALK_OB_TABLE"))
+        if (env[0] == '0') return;              // tuning / A-B knob
+    if (!(d.z_a > 0.0 && d.z_a < 1.0) || !std::isfinite(d.k1) ||
+        !std::isfinite(d.kp1) || !std::isfinite(d.cf))
+        return;
+    std::vector<double> reg[2];
+    int m[2] = { 0, 0 };
+    for (int b = 0; b < 2; ++b) {
+        for (int cand = 16; cand <= OB_MAX_ROWS; cand *= 2) {
+            reg[b].assign((size_t)cand * OB_ROW, 0.0);
+            const double err = ob_build_region(d, b == 1, cand, reg[b].data());
+            g_ob_last_err[b] = err;
+            if (std::isfinite(err) && err <= OB_TOL) { m[b] = cand; break; }
+        }
+        if (!m[b]) return;
+    }
+    // the row map of the kernel is the larger of two lines: the barrier's
+    // intervals must not be wider than the well's
+    const int need2 = (int)std::ceil((double)m[0] * (1.0 - d.z_a) / d.z_a);
+    if (need2 > m[1]) {
+        if (need2 > 8 * OB_MAX_ROWS) return;
+        m[1] = need2;
+        reg[1].assign((size_t)m[1] * OB_ROW, 0.0);
+        const double err = ob_build_region(d, true, m[1], reg[1].data());
+        g_ob_last_err[1] = err;
+        if (!(std::isfinite(err) && err <= OB_TOL)) return;
+    }
+    m1 = m[0]; m2 = m[1];
+    tab = reg[0];
+    tab.insert(tab.end(), reg[1].begin(), reg[1].end());
+    // closing row: z_cell -> 1 rounds into it at t = 0, where the periodic
+    // factor continues with the first well interval
+    tab.insert(tab.end(), reg[0].begin(), reg[0].begin() + OB_ROW);
+}
+
+// Diagnostic, no GPU needed: the table a model would get.
+extern "C" int qmc_model_one_body_table_info(const qmc_model_params *model,
+                                             int32_t *rows_well,
+                                             int32_t *rows_barrier,
+                                             double *max_err)
+{
+    if (!model) return fail("qmc_model_one_body_table_info: null argument");
+    DevModel d;
+    build_dev_model(*model, d);
+    std::vector<double> tab;
+    int m1 = 0, m2 = 0;
+    g_ob_last_err[0] = g_ob_last_err[1] = 0.0;
+    build_ob_table(d, tab, m1, m2);
+    if (rows_well) *rows_well = m1;
+    if (rows_barrier) *rows_barrier = m2;
+    if (max_err) *max_err = fmax(g_ob_last_err[0], g_ob_last_err[1]);
+    return 0;
 }
 
 static int engine_create_impl(const qmc_model_params *model, int device,
@@ -340,6 +553,24 @@ static int engine_create_impl(const qmc_model_params *model, int device,
     }
     HIP_TRY(hipEventCreate(&e->ev0));
     HIP_TRY(hipEventCreate(&e->ev1));
+    {
+        std::vector<double> tab;
+        int m1 = 0, m2 = 0;
+        build_ob_table(e->dm, tab, m1, m2);
+        if (!tab.empty()) {
+            HIP_TRY(hipMalloc((void **)&e->ob_table_dev,
+                              tab.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(e->ob_table_dev, tab.data(),
+                              tab.size() * sizeof(double),
+                              hipMemcpyHostToDevice));
+            DevModel &d = e->dm;
+            d.ob_table = e->ob_table_dev;
+            d.ob_m1 = m1; d.ob_m2 = m2;
+            d.ob_invh1 = (double)m1 / d.z_a;
+            d.ob_invh2 = (double)m2 / (1.0 - d.z_a);
+            d.ob_shift2 = (double)m1 / d.ob_invh2 - d.z_a;
+        }
+    }
     HIP_TRY(hipMalloc((void **)&e->dm_dev, sizeof(DevModel)));
     HIP_TRY(hipMemcpy(e->dm_dev, &e->dm, sizeof(DevModel),
                       hipMemcpyHostToDevice));
@@ -358,6 +589,18 @@ extern "C" int qmc_engine_create_on_stream(const qmc_model_params *model,
                                            qmc_engine **out)
 {
     return engine_create_impl(model, device, stream, true, out);
+}
+
+extern "C" int qmc_engine_set_fast_math(qmc_engine *e, int on, int *in_effect)
+{
+    if (!e) return fail("qmc_engine_set_fast_math: null engine");
+    // available for the one-wavefront-per-walker shapes (boson_number > 32)
+    // unless pairs are classified from positions (cutoff close to L/2);
+    // elsewhere the request is a no-op: the knob grants a permission
+    const bool can = e->G == 64 && !e->dm.zclass && !e->dm.is_ideal;
+    e->fast = on && can;
+    if (in_effect) *in_effect = e->fast ? 1 : 0;
+    return 0;
 }
 
 extern "C" int qmc_engine_stream(qmc_engine *e, void **stream, int *owned)
@@ -418,6 +661,7 @@ extern "C" void qmc_engine_destroy(qmc_engine *e)
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->dm_dev) hipFree(e->dm_dev);
+    if (e->ob_table_dev) hipFree(e->ob_table_dev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }

@@ -110,7 +110,7 @@ class ModelEngine:
     ordered with the engine's kernels (`dist.DistributedDmc` checks it)."""
 
     def __init__(self, cfc_spec, device: t.Optional[int] = None,
-                 stream: t.Optional[int] = None):
+                 stream: t.Optional[int] = None, fast_math: bool = False):
         self._lib = _lib.load()
         self.cfc_spec = cfc_spec
         self.num_particles = int(cfc_spec.model_params.boson_number)
@@ -125,6 +125,20 @@ class ModelEngine:
                 C.byref(self._params), self.device, C.c_void_p(int(stream)),
                 C.byref(h)))
         self._h = h
+        self.fast_math = False
+        if fast_math:
+            self.set_fast_math(True)
+
+    def set_fast_math(self, on: bool) -> bool:
+        """The reference's `jit_fastmath` knob: float pair loop (tables, sums
+        over walkers, one-body factor, logs and the Metropolis test stay in
+        double).  -> whether the variant is in effect for this model (it
+        exists for boson_number > 32 and cutoffs not close to L/2)."""
+        eff = C.c_int(0)
+        check(self._lib.qmc_engine_set_fast_math(self._h, int(bool(on)),
+                                                 C.byref(eff)))
+        self.fast_math = bool(eff.value)
+        return self.fast_math
 
     @property
     def stream_handle(self) -> int:

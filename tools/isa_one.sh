@@ -13,8 +13,8 @@ cat > "$tmp" <<SRC
 #include "$R/phd_qmclib_amd/csrc/qmc_kernels.h"
 template __global__ void $inst(${3:-const DevModel *, VmcArgs});
 SRC
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -DQMC_SECTIONS \
-    -Rpass-analysis=kernel-resource-usage -Wno-unused-value -o "$out" "$tmp" 2>&1 |
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -DQMC_SECTIONS ${QMC_EXTRA:-} \
+    -Rpass-analysis=kernel-resource-usage -Wno-unused-value -fno-slp-vectorize -o "$out" "$tmp" 2>&1 |
     grep -E "remark:.*(Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize)" | sed 's/.*remark: //; s/ \[-Rpass.*//' |
     awk -v k="${inst%%<*}" '/Function Name/ { show = index($0, k) > 0 } show' || true
 python3 "$R/tools/isa_count.py" "$out" --only "${inst%%<*}" --ops
