@@ -580,9 +580,20 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 // costs occupancy through LDS (P = 8: 128 KB per block, one wave per SIMD), so
 // the table is stored once and the rotated index is masked (one v_and per
 // partner table, i.e. per 2-8 pairs).
+// Tile-sweep knobs of the N = 512 shape (BASELINE.json configs[4]: "LDS
+// tile-size sweep"; tools/tile_sweep.sh builds the variants): own particles per
+// rotation pass (the register tile: 64 * QMC_PA8 particles) and copies of the
+// LDS tables.  Defaults = the fastest measured (profiles/r02_n512_tile_sweep.txt).
+#ifndef QMC_PA8
+#define QMC_PA8 8
+#endif
+#ifndef QMC_DUP8
+#define QMC_DUP8 1
+#endif
+
 template <int G, int P, bool ZCLASS>
 struct GroupLds {
-    static constexpr int DUP = (P >= 2) ? 1 : 2;
+    static constexpr int DUP = (P >= 8) ? QMC_DUP8 : ((P >= 2) ? 1 : 2);
     static constexpr int ROW = DUP * G * P;
     static constexpr int DOUBLES = (ZCLASS ? 5 : 4) * ROW;
 };
@@ -606,7 +617,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     // Own particles are processed PA at a time: with P = 8 the tables of all
     // eight (96 VGPRs) would leave one wave per SIMD, so the rotation runs in
     // two passes of four own particles (tables re-read from LDS).
-    constexpr int PA = (P > 4) ? 4 : P;
+    constexpr int PA = (P > 4) ? QMC_PA8 : P;
     constexpr int NPASS = P / PA;
     constexpr bool RD = sizeof(R) == 8;      // the pair loop runs in double
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW,
@@ -615,7 +626,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     // one-case form with a shifted second copy of the tables (pair_core1)
     // (float pair loop only: in double the four-case form below measured
     // 1.3 % faster, in float this one 2.3 % -- profiles/r02_ab_variants.txt)
-    constexpr bool ROTCOPY = (DUP == 2) && !ZCLASS && !RD;
+    constexpr bool ROTCOPY = (P == 1) && (DUP == 2) && !ZCLASS && !RD;
     // four-case short-range form while the own tables fit (see pair_core4)
     constexpr bool FOURCASE = (P <= 2) && !ROTCOPY;
     PTabT<R> t[PA];
@@ -914,6 +925,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         }
         QMC_PASS(0)
         QMC_PASS(1)
+        QMC_PASS(2)
+        QMC_PASS(3)
 #undef QMC_PASS
 #undef QMC_KSTEP
     }

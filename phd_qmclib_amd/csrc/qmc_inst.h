@@ -3,8 +3,7 @@
 // by `make -j`); qmcwalk.hip sees them as `extern template` declarations.
 //
 // Which (PAD, ZC) variants exist follows the dispatch in qmcwalk.hip: shapes
-// with P >= 4 always run the masked (PAD) variant of evaluate / prepare /
-// vmc_step, P == 4 also of dmc_evolve (LaunchX::want_mask).
+// with P >= 4 always run the masked (PAD) variant (LaunchX::want_mask).
 #pragma once
 
 #include "qmc_kernels.h"
@@ -43,19 +42,15 @@
 #define QMC_TU_64_2(KW) QMC_INST_SMALL(KW, 64, 2)
 #define QMC_TU_64_4_Z0(KW) QMC_INST_ALL(KW, 64, 4, true, false)
 #define QMC_TU_64_4_Z1(KW) QMC_INST_ALL(KW, 64, 4, true, true)
-#define QMC_TU_64_8_Z0(KW)                                                    \
-    QMC_INST_ALL(KW, 64, 8, true, false) QMC_INST_EVO(KW, 64, 8, false, false)
-#define QMC_TU_64_8_Z1(KW)                                                    \
-    QMC_INST_ALL(KW, 64, 8, true, true) QMC_INST_EVO(KW, 64, 8, false, true)
+#define QMC_TU_64_8_Z0(KW) QMC_INST_ALL(KW, 64, 8, true, false)
+#define QMC_TU_64_8_Z1(KW) QMC_INST_ALL(KW, 64, 8, true, true)
 
 #define QMC_TU_F32_64_1(KW)                                                   \
     QMC_INST_ALL_F(KW, 64, 1, false) QMC_INST_ALL_F(KW, 64, 1, true)
 #define QMC_TU_F32_64_2(KW)                                                   \
     QMC_INST_ALL_F(KW, 64, 2, false) QMC_INST_ALL_F(KW, 64, 2, true)
 #define QMC_TU_F32_64_4(KW) QMC_INST_ALL_F(KW, 64, 4, true)
-#define QMC_TU_F32_64_8(KW)                                                   \
-    QMC_INST_ALL_F(KW, 64, 8, true)                                           \
-    QMC_INST_EVO_R(KW, 64, 8, false, false, float)
+#define QMC_TU_F32_64_8(KW) QMC_INST_ALL_F(KW, 64, 8, true)
 
 #define QMC_NO_KW
 #define QMC_FOR_ALL_TUS(X)                                                    \

@@ -270,9 +270,9 @@ struct LaunchVmc {
 
 template <int G, int P, bool PAD, bool ZC>
 struct LaunchEvolve {
-    // P = 8 is capped at two waves per SIMD by LDS either way: unmasked
-    // (186 VGPRs) it saves the guards
-    static constexpr bool want_mask(int np) { return np == 4; }
+    // (P = 8: the unmasked variant needs 253 registers and ran 1.7x slower,
+    // profiles/r02_n512_tile_sweep.txt)
+    static constexpr bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const EvolveArgs &a)
     {
         const size_t lds = lds_bytes<G, P, ZC>();
