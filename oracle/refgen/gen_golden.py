@@ -560,7 +560,181 @@ def gen_sweep():
     np.savez_compressed(os.path.join(OUT, 'sweep.npz'), **out)
 
 
-ALL = dict(sweep=gen_sweep, wf_opt=gen_wf_opt, dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
+def gen_vmc_extra():
+    """What round 1 left unpinned on the VMC side:
+      * the static structure factor of a single chain through
+        `Sampling.blocks` (qmc_base/jastrow/vmc.py:304-351), including
+        rejected steps -- where the reference copies the previous row, quirk
+        D6 -- and a block boundary;
+      * the Gaussian-proposal sampling `vmc_ndf` (qmc_base/vmc_ndf.py:43-59,
+        mrbp_qmc/vmc_ndf.py:23-51): N normal draws then one uniform per step.
+    """
+    from phd_qmclib.mrbp_qmc import vmc_ndf
+    out = {}
+    spec = mrbp_qmc.Spec(**SPECS['box8'])
+    n = spec.boson_number
+    # -- S(k) of a single chain
+    np.random.seed(515)
+    ini = spec.init_get_sys_conf()
+    smp = mrbp_qmc.vmc.Sampling(spec, move_spread=0.3, rng_seed=5,
+                                ssf_est_spec=mrbp_qmc.vmc.SSFEstSpec(6))
+    st0 = smp.build_state(ini)
+    ssf, ms, wf, en = [], [], [], []
+    with harness.RNGTape() as tape:
+        for blk in islice(smp.blocks(40, st0), 2):
+            ssf.append(np.array(blk.iter_ssf, copy=True))
+            ms.append(blk.iter_props.move_stat.copy())
+            wf.append(blk.iter_props.wf_abs_log.copy())
+            en.append(blk.iter_props.energy.copy())
+    assert not tape.normal
+    out['ssf8/ini_pos'] = ini[0].copy()
+    out['ssf8/move_spread'] = np.float64(0.3)
+    out['ssf8/num_modes'] = np.int64(6)
+    out['ssf8/uniform'] = np.array(tape.uniform)
+    out['ssf8/iter_ssf'] = np.array(ssf)           # [block, step, mode, 3]
+    out['ssf8/move_stat'] = np.array(ms)
+    out['ssf8/wf_abs_log'] = np.array(wf)
+    out['ssf8/energy'] = np.array(en)
+    print('vmc_extra ssf8 rejected', int((~np.array(ms)).sum()), 'of',
+          np.array(ms).size, np.array(ssf)[0, :3, 1])
+    # -- Gaussian proposal
+    np.random.seed(616)
+    ini = spec.init_get_sys_conf()
+    # (the attrs field order of the reference class starts with the inherited
+    # `move_spread`, which the Gaussian sampling never reads)
+    smp = vmc_ndf.Sampling(move_spread=0.0, model_spec=spec, time_step=0.01,
+                           rng_seed=6)
+    st0 = smp.build_state(ini)
+    ms, wf, en, ar = [], [], [], []
+    with harness.RNGTape() as tape:
+        for blk in islice(smp.blocks(40, st0), 2):
+            ms.append(blk.iter_props.move_stat.copy())
+            wf.append(blk.iter_props.wf_abs_log.copy())
+            en.append(blk.iter_props.energy.copy())
+            ar.append(blk.accept_rate)
+            last = blk.last_state
+    # per step: N normals (proposal) then one uniform (Metropolis)
+    kinds = ''.join(tape.kinds)
+    nsteps = len(tape.uniform)
+    assert kinds == ('n' * n + 'u') * nsteps, kinds[:40]
+    rows = np.concatenate([np.array(tape.normal).reshape(nsteps, n),
+                           np.array(tape.uniform)[:, None]], axis=1)
+    out['ndf8/ini_pos'] = ini[0].copy()
+    out['ndf8/time_step'] = np.float64(0.01)
+    out['ndf8/tape'] = rows                        # [step, N + 1]
+    out['ndf8/move_stat'] = np.array(ms)
+    out['ndf8/wf_abs_log'] = np.array(wf)
+    out['ndf8/energy'] = np.array(en)
+    out['ndf8/accept_rate'] = np.array(ar)
+    out['ndf8/last_pos'] = last.sys_conf[0].copy()
+    print('vmc_extra ndf8', nsteps, ar)
+    np.savez_compressed(os.path.join(OUT, 'vmc_extra.npz'), **out)
+
+
+def gen_proc():
+    """`Proc.exec` of the reference (qmc_exec/vmc/proc.py:87-250,
+    qmc_exec/dmc/proc.py:136-415 through mrbp_qmc/{vmc,dmc}_exec/proc.py) on
+    recorded RNG streams: the block totals / weight totals the driver hands
+    to the reblocking containers, their means and errors, the default
+    burn-in, with and without `keep_iter_data`."""
+    import warnings
+    from phd_qmclib.mrbp_qmc import dmc_exec, vmc_exec
+    out = {}
+    spec = mrbp_qmc.Spec(**SPECS['box8'])
+    n = spec.boson_number
+
+    def blocks_dump(prefix, blk):
+        for name in ('totals', 'weight_totals'):
+            v = getattr(blk, name, None)
+            if v is not None:
+                out[prefix + '/' + name] = np.array(v)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            out[prefix + '/mean'] = np.array(blk.mean)
+            out[prefix + '/mean_error'] = np.array(blk.mean_error)
+
+    # ---------------- VMC ----------------
+    for tag, keep in (('vmc', False), ('vmc_keep', True)):
+        np.random.seed(717)
+        proc = vmc_exec.Proc(spec, move_spread=0.25, rng_seed=8, num_blocks=8,
+                             num_steps_block=20, keep_iter_data=keep,
+                             ssf_spec=vmc_exec.SSFEstSpec(num_modes=5))
+        ini = spec.init_get_sys_conf()
+        pin = vmc_exec.ProcInput(proc.sampling.build_state(ini))
+        with harness.RNGTape() as tape:
+            res = proc.exec(pin)
+        assert not tape.normal
+        out[tag + '/ini_pos'] = ini[0].copy()
+        out[tag + '/cfg'] = np.array([0.25, 8, 20, int(keep), 5])
+        out[tag + '/uniform'] = np.array(tape.uniform)
+        blocks_dump(tag + '/energy', res.data.blocks.energy)
+        blocks_dump(tag + '/ss_factor', res.data.blocks.ss_factor)
+        out[tag + '/last_pos'] = res.state.sys_conf[0].copy()
+        out[tag + '/last_wf_abs_log'] = np.float64(res.state.wf_abs_log)
+        # default burn-in: num_blocks // 8 blocks (qmc_exec/vmc/proc.py:123-126)
+        assert len(tape.uniform) == (8 + 1) * 20 * (n + 1) - (n + 1), \
+            len(tape.uniform)
+        print('proc', tag, out[tag + '/energy/totals'][:3],
+              out[tag + '/energy/mean'])
+    # ---------------- DMC ----------------
+    for tag, keep, est in (('dmc', False, False), ('dmc_keep', True, False),
+                           ('dmc_est', False, True)):
+        np.random.seed(818)
+        kw = {}
+        if est:
+            kw = dict(ssf_spec=dmc_exec.SSFEstSpec(num_modes=4,
+                                                   as_pure_est=True),
+                      density_spec=dmc_exec.DensityEstSpec(
+                          num_bins=8, as_pure_est=False))
+        proc = dmc_exec.Proc(spec, time_step=1e-3, max_num_walkers=48,
+                             target_num_walkers=24, rng_seed=9, num_blocks=8,
+                             num_time_steps_block=6, keep_iter_data=keep,
+                             jit_parallel=False, **kw)
+        # (the concrete class overrides the base post-init, so the default
+        # stays None and `exec` burns num_blocks // 8 blocks)
+        assert proc.burn_in_blocks is None
+        assert proc.num_walkers_control_factor == 0.5
+        ini_set = np.array([spec.init_get_sys_conf() for _ in range(20)])
+        pin = dmc_exec.ProcInput(proc.sampling.build_state(ini_set))
+        with harness.RNGTape() as tape:
+            res = proc.exec(pin)
+        # segment the streams per time step: uniforms (branching) then
+        # normals (diffusion)
+        kinds = ''.join(tape.kinds)
+        n_u, n_n, i = [], [], 0
+        while i < len(kinds):
+            j = i
+            while j < len(kinds) and kinds[j] == 'u':
+                j += 1
+            k = j
+            while k < len(kinds) and kinds[k] == 'n':
+                k += 1
+            n_u.append(j - i)
+            n_n.append(k - j)
+            i = k
+        assert len(n_u) == (8 + 1) * 6, len(n_u)
+        out[tag + '/ini_pos'] = ini_set[:, 0, :].copy()
+        out[tag + '/cfg'] = np.array([1e-3, 48, 24, 0.5, 8, 6, int(keep)])
+        out[tag + '/uniform'] = np.array(tape.uniform)
+        out[tag + '/normal'] = np.array(tape.normal)
+        out[tag + '/n_uniform'] = np.array(n_u)
+        out[tag + '/n_normal'] = np.array(n_n)
+        b = res.data.blocks
+        blocks_dump(tag + '/energy', b.energy)
+        blocks_dump(tag + '/weight', b.weight)
+        blocks_dump(tag + '/num_walkers', b.num_walkers)
+        if est:
+            blocks_dump(tag + '/ss_factor', b.ss_factor)
+            blocks_dump(tag + '/density', b.density)
+        out[tag + '/last_num_walkers'] = np.int64(res.state.num_walkers)
+        out[tag + '/last_ref_energy'] = np.float64(res.state.ref_energy)
+        print('proc', tag, out[tag + '/energy/totals'][:3],
+              out[tag + '/energy/weight_totals'][:3], out[tag + '/energy/mean'],
+              out[tag + '/num_walkers/totals'][:3])
+    np.savez_compressed(os.path.join(OUT, 'proc_exec.npz'), **out)
+
+
+ALL = dict(proc=gen_proc, vmc_extra=gen_vmc_extra, sweep=gen_sweep, wf_opt=gen_wf_opt, dmc_est=gen_dmc_est, params=gen_params, kernels=gen_kernels, vmc_tape=gen_vmc_tape,
            dmc_tape=gen_dmc_tape, reblock=gen_reblock, stats=gen_stats)
 
 if __name__ == '__main__':

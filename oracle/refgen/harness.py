@@ -57,6 +57,7 @@ class RNGTape:
     def __init__(self):
         self.uniform = []
         self.normal = []
+        self.kinds = []        # 'u' / 'n' per draw, in call order
         self._rand = np.random.rand
         self._normal = np.random.normal
 
@@ -65,6 +66,7 @@ class RNGTape:
             assert not a
             v = self._rand()
             self.uniform.append(v)
+            self.kinds.append('u')
             return v
 
         def normal(loc=0.0, scale=1.0, size=None):
@@ -73,6 +75,7 @@ class RNGTape:
             assert size is None
             g = self._normal()
             self.normal.append(g)
+            self.kinds.append('n')
             return loc + scale * g
 
         np.random.rand = rand

@@ -6,8 +6,9 @@ attrs fields and defaults, `build_state`, `states`, `blocks`,
 behind a `qmc_dmc` handle; a block of time steps is enqueued without a host
 round trip and only the per-step series come back.
 
-`jit_parallel` / `jit_fastmath` are accepted for drop-in compatibility and
-ignored (there is no numba here).  `fix_stale_energy` is an extension: False
+`jit_parallel` is accepted for drop-in compatibility (there is no numba here);
+`jit_fastmath` selects the engine's reduced-precision pair loop (float), as in
+the reference only together with `jit_parallel`.  `fix_stale_energy` is an extension: False
 reproduces the reference's branching weight, True uses the
 parent's energy.  The density / S(k) estimators (mixed and pure /
 forward-walking) run on the device after every kept
@@ -160,10 +161,32 @@ class Sampling:
         return model.core_funcs
 
     # -- engine plumbing --------------------------------------------------------
+    def set_replay_tape(self, uniform, normal, n_uniform, n_normal):
+        """TEST ONLY: the next generator replays recorded streams instead of
+        Philox: the uniforms of the branching loop and the standard normals
+        of the diffusion, with the number of draws of every time step."""
+        if uniform is None:
+            object.__setattr__(self, '_replay_tape', None)
+            return
+        u_off = np.concatenate([[0], np.cumsum(n_uniform)[:-1]])
+        g_off = np.concatenate([[0], np.cumsum(n_normal)[:-1]])
+        object.__setattr__(self, '_replay_tape',
+                           (np.asarray(uniform, dtype=np.float64),
+                            np.asarray(normal, dtype=np.float64),
+                            u_off.astype(np.int64), g_off.astype(np.int64)))
+
+    @property
+    def fast_math_in_effect(self) -> bool:
+        """`jit_fastmath` asks for the reduced-precision pair loop; as in the
+        reference it only takes effect together with `jit_parallel`
+        (mrbp_qmc/dmc.py:647-654: the (False, True) entry of the core
+        functions table is built without fastmath)."""
+        return bool(self.jit_parallel and self.jit_fastmath)
+
     def _new_ensemble(self, target=None, slot0=0, device=None, stream=None,
                       external_reduce=False):
         eng = ModelEngine(self.model_spec.cfc_spec, device=device,
-                          stream=stream)
+                          stream=stream, fast_math=self.fast_math_in_effect)
         ens = DmcEnsemble(eng, self.time_step, self.max_num_walkers,
                           target if target is not None
                           else self.target_num_walkers,
@@ -226,6 +249,9 @@ class Sampling:
         ens.set_full_state(ini_state.confs[:nw], ini_state.props.energy[:nw],
                            ini_state.props.weight[:nw], ini_state.ref_energy,
                            slot_energy=ini_state.props.energy)
+        tape = getattr(self, '_replay_tape', None)
+        if tape is not None:
+            ens.set_tape(*tape)
         return eng, ens
 
     # -- generators (qmc_base/dmc.py:311-364) ---------------------------------

@@ -1,6 +1,7 @@
 """DMC procedure of the Bloch-Phonon model (reference:
 mrbp_qmc/dmc_exec/proc.py:161-398): same fields and defaults (512 blocks x 512
 time steps, 480 target / 512 max walkers, control factor 0.5)."""
+import functools
 import typing as t
 import warnings
 
@@ -125,7 +126,7 @@ class Proc:
     def should_eval_ssf(self):
         return self.ssf_spec is not None
 
-    @property
+    @functools.cached_property
     def sampling(self) -> dmc.Sampling:
         """dmc_exec/proc.py:336-371: the forward walking of the pure
         estimators spans one block."""

@@ -133,12 +133,23 @@ class Sampling:
         wf = model.core_funcs.wf_abs_log(sys_conf, *self.model_spec.cfc_spec)
         return vmc_base.State(sys_conf, wf, STAT_ACCEPTED)
 
+    def set_replay_tape(self, tape):
+        """TEST ONLY: the next generator replays a recorded random stream
+        instead of Philox -- tape[steps, N + 1] = the N proposal draws and
+        the accept uniform of every step, in the reference's call order."""
+        object.__setattr__(self, '_replay_tape',
+                           None if tape is None else
+                           np.ascontiguousarray(tape, dtype=np.float64))
+
     def _start(self, ini_state: vmc_base.State):
         eng = self._engine()
         ens = VmcEnsemble(eng, 1, self._proposal_width(), self.rng_seed,
                           gaussian=self._gaussian)
         pos = np.asarray(ini_state.sys_conf, dtype=np.float64)[model.SysConfSlot.pos]
         ens.set_state(pos[None, :])
+        tape = getattr(self, '_replay_tape', None)
+        if tape is not None:
+            ens.set_tape(tape[None, :, :])
         return eng, ens
 
     def _state_from(self, ens, wf, move_stat):

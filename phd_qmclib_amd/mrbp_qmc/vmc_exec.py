@@ -1,5 +1,6 @@
 """VMC procedure of the Bloch-Phonon model (reference:
 mrbp_qmc/vmc_exec/proc.py:155-299): same fields and defaults."""
+import functools
 import typing as t
 import warnings
 
@@ -124,7 +125,7 @@ class Proc:
     def should_eval_ssf(self):
         return self.ssf_spec is not None
 
-    @property
+    @functools.cached_property
     def sampling(self) -> vmc.Sampling:
         ssf = vmc.SSFEstSpec(self.ssf_spec.num_modes) \
             if self.should_eval_ssf else None

@@ -427,50 +427,76 @@ def test_ensemble_sampling_ssf():
     smp.close()
 
 
+def _z(a, b):
+    """(mean a - mean b) in units of the combined standard error; a, b are
+    independent samples (chains / runs)."""
+    return (a.mean() - b.mean()) / np.sqrt(a.var(ddof=1) / len(a) +
+                                           b.var(ddof=1) / len(b))
+
+
 def test_vmc_n64_statistics_vs_oracle(oracle):
     """The north-star gate at the benchmarked size (N = 64, where the reference
-    itself is too slow to sample): block-averaged energy and acceptance of the
-    device ensemble against the pinned CPU oracle run with independent chains,
-    within 2.5 sigma of the combined Monte Carlo error (fixed seeds)."""
+    itself is too slow to sample): block-averaged energy, VARIANCE of the
+    local energy and acceptance of the device ensemble against the pinned CPU
+    oracle, independent chains, THREE seeds on each side.
+
+    Gate (BASELINE.json north_star, SURVEY 8d "parity gate"): each quantity
+    pooled over the three seeds within 2 sigma of the combined Monte Carlo
+    error, and every single seed-against-seed comparison within 3 sigma.
+    Nominal false-alarm probability: 4.6 % per pooled quantity (three
+    quantities), 0.27 % per single comparison; the seeds are fixed and both
+    generators are counter-based, so a given build always reproduces the same
+    z values -- they are printed for the record."""
     from phd_qmclib_amd.engine import ModelEngine, VmcEnsemble
     spec = box(64)
     m = oracle.model_from_cfc(spec.cfc_spec)
     burn, ns = 300, 500
-    # oracle: 384 chains
-    Wo = 384
-    pos = 64 * np.random.RandomState(8).random_sample((Wo, 64))
-    wf = np.array([oracle.wf_abs_log(m, p) for p in pos])
-    ec = np.zeros(Wo)
-    oracle.vmc_ensemble(m, pos, wf, ec, 0.125, 77, burn, yield_initial=True)
-    se, _, na = oracle.vmc_ensemble(m, pos, wf, ec, 0.125, 77, ns,
-                                    step0=burn)
-    eo = se / ns / 64
-    # device: 8192 chains, other seed
+    Wo, Wg = 512, 8192
     eng = ModelEngine(spec.cfc_spec)
-    Wg = 8192
-    v = VmcEnsemble(eng, Wg, 0.125, rng_seed=1234)
-    v.set_state(64 * np.random.RandomState(9).random_sample((Wg, 64)))
-    v.run_block(burn, sums=False)
-    out = v.run_block(ns)
-    eg = out['sum_energy'] / ns / 64
-    z = (eg.mean() - eo.mean()) / np.sqrt(eg.var(ddof=1) / Wg +
-                                          eo.var(ddof=1) / Wo)
-    assert abs(z) < 2.5, (z, eg.mean(), eo.mean())
-    acc_g = out['num_accepted'] / ns
-    acc_o = na / ns
-    za = (acc_g.mean() - acc_o.mean()) / np.sqrt(acc_g.var(ddof=1) / Wg +
-                                                 acc_o.var(ddof=1) / Wo)
-    assert abs(za) < 2.5, (za, acc_g.mean(), acc_o.mean())
-    # the chain-to-chain spread itself is the same distribution
-    assert eg.std(ddof=1) == pytest.approx(eo.std(ddof=1), rel=0.15)
-    v.close(); eng.close()
+    dev, orc = [], []
+    for k in range(3):
+        pos = 64 * np.random.RandomState(80 + k).random_sample((Wo, 64))
+        wf = np.array([oracle.wf_abs_log(m, p) for p in pos])
+        ec = np.zeros(Wo)
+        oracle.vmc_ensemble(m, pos, wf, ec, 0.125, 770 + k, burn,
+                            yield_initial=True)
+        se, se2, na = oracle.vmc_ensemble(m, pos, wf, ec, 0.125, 770 + k, ns,
+                                          step0=burn)
+        orc.append(dict(e=se / ns / 64, acc=na / ns,
+                        var=(se2 / ns - (se / ns) ** 2) / 64 ** 2))
+        v = VmcEnsemble(eng, Wg, 0.125, rng_seed=1234 + k)
+        v.set_state(64 * np.random.RandomState(90 + k)
+                    .random_sample((Wg, 64)))
+        v.run_block(burn, sums=False)
+        out = v.run_block(ns)
+        dev.append(dict(
+            e=out['sum_energy'] / ns / 64, acc=out['num_accepted'] / ns,
+            var=(out['sum_energy2'] / ns - (out['sum_energy'] / ns) ** 2)
+            / 64 ** 2))
+        v.close()
+    eng.close()
+    report = {}
+    for q in ('e', 'var', 'acc'):
+        pooled = _z(np.concatenate([d[q] for d in dev]),
+                    np.concatenate([o[q] for o in orc]))
+        single = [_z(d[q], o[q]) for d in dev for o in orc]
+        report[q] = (float(pooled), [round(float(x), 2) for x in single])
+    print('N=64 VMC z values (pooled, singles):', report)
+    for q, (pooled, single) in report.items():
+        assert abs(pooled) < 2.0, (q, report)
+        assert max(abs(x) for x in single) < 3.0, (q, report)
+    # and the numbers are the physical ones (VMC energy of the trial state)
+    assert 15.5 < np.concatenate([d['e'] for d in dev]).mean() < 15.95
 
 
 def test_dmc_n64_statistics_vs_oracle(oracle):
     """Same gate for DMC at N = 64: independent ensembles of 128 walkers (same
-    population, hence the same population-control bias) on the device and in
-    the oracle; time-averaged E/N and mean population agree (pooled t-test over
-    the runs, |t| < 3.4 at 12 degrees of freedom)."""
+    population, hence the same population-control bias) on the device (16
+    seeds) and in the oracle (8 seeds); time-averaged E/N and mean population
+    within the 2-sigma-equivalent of Welch's t (the run-to-run spread is
+    estimated from 8 and 16 runs, so the critical value is Student's, not the
+    normal 2.0: same 4.6 % nominal false-alarm probability per quantity)."""
+    from scipy import stats
     from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
     spec = box(64)
     m = oracle.model_from_cfc(spec.cfc_spec)
@@ -497,15 +523,18 @@ def test_dmc_n64_statistics_vs_oracle(oracle):
             e += y.energy; w += y.weight; nw += y.num_walkers
         return e / w / 64, nw / ns
 
-    dev = np.array([dev_run(100 + k) for k in range(10)])
-    orc = np.array([orc_run(200 + k) for k in range(4)])
+    dev = np.array([dev_run(100 + k) for k in range(16)])
+    orc = np.array([orc_run(200 + k) for k in range(8)])
+    report = {}
     for col, name in ((0, 'E/N'), (1, '<nw>')):
-        # same process on both sides -> pooled run-to-run variance (12 dof)
-        nd, no = len(dev), len(orc)
-        pooled = ((nd - 1) * dev[:, col].var(ddof=1) +
-                  (no - 1) * orc[:, col].var(ddof=1)) / (nd + no - 2)
-        t = (dev[:, col].mean() - orc[:, col].mean()) / np.sqrt(
-            pooled * (1 / nd + 1 / no))
-        assert abs(t) < 3.4, (name, t, dev[:, col], orc[:, col])
+        a, b = dev[:, col], orc[:, col]
+        va, vb = a.var(ddof=1) / len(a), b.var(ddof=1) / len(b)
+        t = (a.mean() - b.mean()) / np.sqrt(va + vb)
+        dof = (va + vb) ** 2 / (va ** 2 / (len(a) - 1) + vb ** 2 / (len(b) - 1))
+        crit = stats.t.ppf(1 - 0.0455 / 2, dof)      # "2 sigma" for Student's t
+        report[name] = (float(t), float(crit), float(a.mean()), float(b.mean()))
+    print('N=64 DMC t values (t, 2-sigma critical value, dev, oracle):', report)
+    for name, (t, crit, _, _) in report.items():
+        assert abs(t) < crit, (name, report)
     assert 14.5 < dev[:, 0].mean() < 16.5
     eng.close()

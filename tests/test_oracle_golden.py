@@ -1,10 +1,12 @@
 """Pins the CPU oracle (oracle/qmc_oracle.c) to the reference: every check
 compares against vectors the reference's own function bodies produced
 (tests/golden/, generator: oracle/refgen/gen_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 
-from .conftest import oracle_model
+from .conftest import GOLDEN, oracle_model
 
 TAGS = ['box8', 'box16', 'box64', 'box128', 'box512', 'free16', 'deep100',
         'deep16', 'ideal16', 'defect24', 'odd24']
@@ -115,3 +117,26 @@ def test_philox_known_answer(oracle):
     # KAT: ctr=ff.. key=ff.. -> 408f276d 41c83b0e a20bc7c6 6d5451fd
     assert u[0] == u53(0x408f276d, 0x41c83b0e)
     assert u[1] == u53(0xa20bc7c6, 0x6d5451fd)
+
+
+def test_vmc_ndf_tape_replay(oracle, golden_params):
+    """Gaussian-proposal VMC (qmc_base/vmc_ndf.py:43-59, mrbp_qmc/vmc_ndf.py):
+    the oracle's chain on the reference's recorded normal()/rand() streams --
+    pins the oracle path the device's `NDFSampling` is compared with."""
+    g = np.load(os.path.join(GOLDEN, 'vmc_extra.npz'), allow_pickle=False)
+    m = oracle_model(oracle, golden_params, 'box8')
+    sigma = float(np.sqrt(g['ndf8/time_step']))
+    ch = oracle.VmcChain(m, g['ndf8/ini_pos'], sigma, gaussian=True)
+    tape = g['ndf8/tape']
+    nblocks, ns = g['ndf8/wf_abs_log'].shape
+    off = 0
+    for b in range(nblocks):
+        real = ns - (1 if b == 0 else 0)
+        wf, en, st, acc = ch.run(ns, tape[off:off + real].ravel())
+        off += real
+        assert np.array_equal(st, g['ndf8/move_stat'][b])
+        assert np.array_equal(wf, g['ndf8/wf_abs_log'][b])
+        assert np.array_equal(en, g['ndf8/energy'][b])
+        assert acc / ns == g['ndf8/accept_rate'][b]
+    assert off == len(tape)
+    assert np.array_equal(ch.pos, g['ndf8/last_pos'])
