@@ -63,7 +63,7 @@ def exec_vmc(proc, proc_input):
     energy_blocks = vmc_data.EnergyBlocks.from_data(props, bool(keep))
     ssf_blocks = None
     if ssf is not None:
-        ssf_blocks = vmc_data.PropBlocks(ssf.mean(axis=1) if keep else ssf)
+        ssf_blocks = vmc_data.SSFBlocks.from_data(ssf, bool(keep))
     data = vmc_data.SamplingData(
         vmc_data.PropsDataBlocks(energy_blocks, ssf_blocks),
         (props, ssf) if keep else None)

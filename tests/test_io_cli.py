@@ -257,8 +257,9 @@ def test_vmc_result_file_roundtrip(tmp_path):
         rng_seed=2, ssf_spec=dict(num_modes=3)))
     rng = np.random.RandomState(1)
     state = vmc_base.State(rng.rand(2, 16), -3.25, 1)
-    data = vd.SamplingData(vd.PropsDataBlocks(vd.EnergyBlocks(rng.rand(5)),
-                                              vd.PropBlocks(rng.rand(5, 3, 3))))
+    data = vd.SamplingData(vd.PropsDataBlocks(
+        vd.EnergyBlocks(rng.rand(5)),
+        vd.SSFBlocks.from_data(rng.rand(5, 3, 3), reduce_data=False)))
     h = vmc_exec.HDF5FileHandler(tmp_path / 'v.h5', 'g0')
     h.dump(vmc_exec.ProcResult(state, proc, data))
     back = h.load()
@@ -267,8 +268,10 @@ def test_vmc_result_file_roundtrip(tmp_path):
     assert back.state.wf_abs_log == -3.25 and back.state.move_stat == 1
     assert np.array_equal(back.data.blocks.energy.totals,
                           data.blocks.energy.totals)
-    assert np.array_equal(back.data.blocks.ss_factor.totals,
-                          data.blocks.ss_factor.totals)
+    for part in ('fdk_sqr_abs_part', 'fdk_real_part', 'fdk_imag_part'):
+        assert np.array_equal(getattr(back.data.blocks.ss_factor, part).totals,
+                              getattr(data.blocks.ss_factor, part).totals)
+    assert back.data.blocks.ss_factor.mean.shape == (3,)
     with h5lite.open_file(h.location, 'r') as f:
         assert sorted(f['g0/vmc/data/blocks/ss_factor'].keys()) == [
             'fdk_imag', 'fdk_real', 'fdk_sqr_abs']
@@ -354,7 +357,7 @@ def test_cli_end_to_end(tmp_path):
     assert vres.proc == app.app_spec[0].proc
     assert np.array_equal(vres.data.blocks.energy.totals,
                           results[0].data.blocks.energy.totals)
-    assert vres.data.blocks.ss_factor.totals.shape == (6, 5, 3)
+    assert vres.data.blocks.ss_factor.fdk_real_part.totals.shape == (6, 5)
     assert np.array_equal(vres.state.sys_conf, results[0].state.sys_conf)
     dpath = _yaml_config(tmp_path, 'dmc', '''\
         time_step: 1e-3
