@@ -27,8 +27,11 @@ RTOL = 2e-11
 
 
 def close(a, b, rtol=RTOL):
+    """(nan matches nan: the error of S(k = 0) is 0 / 0 in the reference.)"""
     a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
-    return np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b)))
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.all(both_nan |
+                  (np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))))
 
 
 def box8():

@@ -491,11 +491,19 @@ def test_vmc_n64_statistics_vs_oracle(oracle):
 
 def test_dmc_n64_statistics_vs_oracle(oracle):
     """Same gate for DMC at N = 64: independent ensembles of 128 walkers (same
-    population, hence the same population-control bias) on the device (16
-    seeds) and in the oracle (8 seeds); time-averaged E/N and mean population
+    population, hence the same population-control bias) on the device (96
+    seeds) and in the oracle (24 seeds); time-averaged E/N and mean population
     within the 2-sigma-equivalent of Welch's t (the run-to-run spread is
-    estimated from 8 and 16 runs, so the critical value is Student's, not the
-    normal 2.0: same 4.6 % nominal false-alarm probability per quantity)."""
+    estimated from the runs themselves, so the critical value is Student's:
+    same 4.6 % nominal false-alarm probability per quantity).
+
+    Before that, the stronger statement the counter-based generator allows:
+    on EQUAL seeds the device follows the oracle's trajectory, so both
+    quantities agree to rounding run by run -- the two sides are the same
+    process in law, and the independent-seed gate measures nothing but
+    Monte-Carlo noise.  (For the record: a first choice of 16 + 8 seeds gave
+    t = 2.8 for the mean population, a 1 % event; the same comparison with 96
+    + 24 other seeds gives |t| < 1, and the equal-seed runs are identical.)"""
     from scipy import stats
     from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
     spec = box(64)
@@ -523,8 +531,12 @@ def test_dmc_n64_statistics_vs_oracle(oracle):
             e += y.energy; w += y.weight; nw += y.num_walkers
         return e / w / 64, nw / ns
 
-    dev = np.array([dev_run(100 + k) for k in range(16)])
-    orc = np.array([orc_run(200 + k) for k in range(8)])
+    orc = np.array([orc_run(3000 + k) for k in range(24)])
+    # equal seeds: the same trajectories (500 steps of branching decisions)
+    same = np.array([dev_run(3000 + k) for k in range(3)])
+    assert np.array_equal(same[:, 1], orc[:3, 1])
+    assert np.allclose(same[:, 0], orc[:3, 0], rtol=1e-9, atol=0)
+    dev = np.array([dev_run(1000 + k) for k in range(96)])
     report = {}
     for col, name in ((0, 'E/N'), (1, '<nw>')):
         a, b = dev[:, col], orc[:, col]
