@@ -14,5 +14,5 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $out/pmc2 -- python3 $R/tools/prof_workload.py "$@" > $out/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc3 -- python3 $R/tools/prof_workload.py "$@" > $out/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc4 -- python3 $R/tools/prof_workload.py "$@" > $out/pmc4.log 2>&1
-python3 $R/tools/pmc_summary.py $out > $out/summary.txt 2>&1
+python3 $R/tools/pmc_summary.py $out ${PMC_LAST:+--last $PMC_LAST} > $out/summary.txt 2>&1
 cat $out/summary.txt
