@@ -45,6 +45,7 @@
 
 struct DevModel {
     int n;                 // boson_number
+    int ge;                // lanes of a group in use (padded shapes, see lane_particle)
     int is_free, is_ideal;
     int defects_sep;
     int zclass;            // classify pairs from positions (rm close to L/2)
@@ -155,6 +156,26 @@ __device__ __forceinline__ double wrap_box(double z, double L)
     return z;
 }
 
+// Particle held by (lane gl, register p) of a lane group, or n (= none).
+// A shape that fits the model exactly uses all G lanes: i = gl + G p.  A
+// padded shape (N < G P) uses only the first ge = 2 ceil(N / 2P) lanes of the
+// group, i = gl + ge p, and rotates over those: N = 100 on the (64, 2) shape
+// runs 25 rotation steps over 50 lanes instead of 32 over 64 (round 1 paid the
+// full shape: 4.7e11 pair evaluations/s at N = 100 against 8.0e11 at N = 128).
+template <int G, bool PAD>
+__device__ __forceinline__ int lanes_in_use(const DevModel &m)
+{
+    return PAD ? m.ge : G;
+}
+
+template <int G, bool PAD>
+__device__ __forceinline__ int lane_particle(const DevModel &m, int gl, int p)
+{
+    if (!PAD) return gl + G * p;
+    const int ge = m.ge;
+    return gl < ge ? gl + ge * p : m.n;
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -178,15 +199,17 @@ __device__ __forceinline__ double group_sum(double v)
 template <int G, int P>
 __device__ __forceinline__ void resort_step(double (&z)[P], int (&lab)[P],
                                             int gl, unsigned parity, int n,
-                                            double L, double half_L)
+                                            double L, double half_L,
+                                            int ge = G)
 {
     const int lane = threadIdx.x & 63, base = lane - gl;
     // partner in the row: even phase (0,1)(2,3)..; odd phase (1,2)(3,4)..
-    // and, across the row seam, (G-1 of row a, 0 of row a+1) cyclically
+    // and, across the row seam, (ge-1 of row a, 0 of row a+1) cyclically
+    // (ge, the lanes in use, is even: every lane has exactly one partner)
     int pg = (parity & 1u) ? ((gl & 1) ? gl + 1 : gl - 1) : (gl ^ 1);
-    const bool wrap_hi = pg >= G, wrap_lo = pg < 0;
+    const bool wrap_hi = pg >= ge, wrap_lo = pg < 0;
     if (wrap_hi) pg = 0;
-    if (wrap_lo) pg = G - 1;
+    if (wrap_lo) pg = ge - 1;
     double z0[P]; int l0[P];
 #pragma unroll
     for (int a = 0; a < P; ++a) { z0[a] = z[a]; l0[a] = lab[a]; }
@@ -201,7 +224,8 @@ __device__ __forceinline__ void resort_step(double (&z)[P], int (&lab)[P],
             int ll = __shfl(l0[b], base + pg, 64);
             if (b == want) { zp = zz; lp = ll; }
         }
-        const bool valid = (gl + G * a) < n && (pg + G * want) < n;
+        const bool valid = gl < ge && (gl + ge * a) < n &&
+                           (pg + ge * want) < n;
         // "lower" = the element whose rank comes first in the cyclic order
         const bool lower = wrap_hi ? true : (wrap_lo ? false : gl < pg);
         double d = lower ? zp - z0[a] : z0[a] - zp;   // upper minus lower
@@ -623,6 +647,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW,
       *lCU = lS + 3 * ROW, *lZ = lS + 4 * ROW;
     const int n = m.n;
+    const int ge = lanes_in_use<G, PAD>(m);   // lanes the rotation runs over
     // one-case form with a shifted second copy of the tables (pair_core1)
     // (float pair loop only: in double the four-case form below measured
     // 1.3 % faster, in float this one 2.3 % -- profiles/r02_ab_variants.txt)
@@ -657,7 +682,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     QMC_SECTION("tables+onebody");
 #pragma unroll
     for (int a = 0; a < P; ++a) {
-        ok[a] = !PAD || (gl + G * a) < n;
+        ok[a] = !PAD || lane_particle<G, PAD>(m, gl, a) < n;
         F[a] = 0.0; T[a] = 0; Kown[a] = 0; KT[a] = 0;
         if (ITH) kin1[a] = 0.0;
         // the one-body factor first: its table rows (or its transcendental
@@ -721,11 +746,14 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 }
             }
             int i0 = a * DUP * G + gl;
-            if (ROTCOPY) {
+            // (idle lanes of a padded shape must not write: with two copies
+            // their slot is another lane's)
+            if (PAD && gl >= ge) {
+            } else if (ROTCOPY) {
                 // upper copy: the particle itself; lower copy (read when the
                 // partner index wraps): the particle one period below
-                lS[i0 + G] = (R)ta.s; lC[i0 + G] = (R)ta.c;
-                lSU[i0 + G] = (R)ta.su; lCU[i0 + G] = (R)ta.cu;
+                lS[i0 + ge] = (R)ta.s; lC[i0 + ge] = (R)ta.c;
+                lSU[i0 + ge] = (R)ta.su; lCU[i0 + ge] = (R)ta.cu;
                 lS[i0] = (R)-ta.s; lC[i0] = (R)-ta.c;
                 lSU[i0] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
                 lCU[i0] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
@@ -734,9 +762,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 lSU[i0] = (R)ta.su; lCU[i0] = (R)ta.cu;
                 if (ZCLASS) lZ[i0] = (R)z[a];
                 if (DUP == 2) {
-                    lS[i0 + G] = (R)ta.s; lC[i0 + G] = (R)ta.c;
-                    lSU[i0 + G] = (R)ta.su; lCU[i0 + G] = (R)ta.cu;
-                    if (ZCLASS) lZ[i0 + G] = (R)z[a];
+                    lS[i0 + ge] = (R)ta.s; lC[i0 + ge] = (R)ta.c;
+                    lSU[i0 + ge] = (R)ta.su; lCU[i0 + ge] = (R)ta.cu;
+                    if (ZCLASS) lZ[i0 + ge] = (R)z[a];
                 }
             }
         } else if (NPASS == 1) {
@@ -821,25 +849,33 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 
         // ---- k = 1 .. G/2: rotate over partner lanes ----
         const int lane = threadIdx.x & 63;
-        const int src = lane - gl + ((gl + G - 1) & (G - 1));
+        // the lane below in the ring of the ge lanes in use
+        const int src = lane - gl + (PAD ? (gl == 0 ? ge - 1 : gl - 1)
+                                         : ((gl + G - 1) & (G - 1)));
+        // ... and the lane half a ring away (delivery of the travelling sums)
+        int half_src = gl + ge / 2;
+        if (half_src >= ge) half_src -= ge;
+        half_src += lane - gl;
         // One rotation step of pass H (own particles H*PA .. H*PA+PA-1);
         // LAST is a compile-time flag: the final half step (k = G/2) visits
         // every pair from both sides, so each side only updates its own
         // particle and the lower half of the lanes tallies.
 #define QMC_KSTEP(H, k, LAST)                                                 \
         {                                                                     \
-            const bool count_pair = !(LAST) || gl < G / 2;                    \
+            const bool count_pair = !(LAST) || gl < ge / 2;                   \
             /* partner-major order: one partner table live at a time */       \
             _Pragma("unroll")                                                 \
             for (int b = 0; b < P; ++b) {                                     \
                 PTabT<R> pb;                                                  \
-                const int idx = (DUP == 2) ? b * 2 * G + gl + G - (k)         \
-                                           : b * G + ((gl - (k)) & (G - 1));  \
+                int pl = gl - (k);                                            \
+                if (PAD) { if (pl < 0) pl += ge; } else pl &= G - 1;          \
+                const int idx = (DUP == 2) ? b * 2 * G + gl + ge - (k)        \
+                                           : b * G + pl;                      \
                 pb.s = lS[idx]; pb.c = lC[idx];                               \
                 pb.su = lSU[idx]; pb.cu = lCU[idx];                           \
                 const R pz = ZCLASS ? lZ[idx] : (R)0;                         \
-                int pl = gl - (k); if (pl < 0) pl += G;                       \
-                const bool pok = !PAD || (pl + G * b) < n;                    \
+                const bool pok = !PAD ||                                      \
+                    (gl < ge && pl + ge * b < n);                             \
                 _Pragma("unroll")                                             \
                 for (int a = 0; a < PA; ++a) {                                \
                     constexpr int ao_base = (H) * PA;                         \
@@ -848,8 +884,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                         pair_core1<R>(pc, t[a].s, t[a].c,                     \
                                       os1[ROTCOPY ? a : 0], aks[a], akc[a],   \
                                       pb, gl < (k),                           \
-                                      lSU[a * DUP * G + G + gl],              \
-                                      lCU[a * DUP * G + G + gl], q, Y, sh,    \
+                                      lSU[a * DUP * G + ge + gl],             \
+                                      lCU[a * DUP * G + ge + gl], q, Y, sh,   \
                                       shm);                                   \
                     else if (FOURCASE)                                        \
                         pair_core4<ZCLASS, R>(pc, t[a],                       \
@@ -907,18 +943,20 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             /* (kept rolled: unrolled, the scheduler hoists the LDS reads of \
                every copy and the kernel loses half its occupancy: -8 %) */  \
             QMC_SECTION("rotation_loop_body");                                \
-            for (int k = 1; k < G / 2; ++k)                                   \
+            for (int k = 1; k < ge / 2; ++k)                                  \
                 QMC_KSTEP(H, k, false)                                        \
             QMC_SECTION("rotation_last_step");                                \
-            QMC_KSTEP(H, G / 2, true)                                         \
+            QMC_KSTEP(H, ge / 2, true)                                        \
             /* deliver the travelling sums to their owners (lane gl ^ G/2    \
                holds them) and start the next pass from zero */              \
             _Pragma("unroll")                                                 \
             for (int b = 0; b < P; ++b) {                                     \
-                Fr[b] += __shfl_xor(T[b], G / 2, 64);                         \
+                Fr[b] += PAD ? __shfl(T[b], half_src, 64)                     \
+                             : __shfl_xor(T[b], G / 2, 64);                   \
                 T[b] = 0;                                                     \
                 if (ITH) {                                                    \
-                    Kown[b] += __shfl_xor(KT[b], G / 2, 64);                  \
+                    Kown[b] += PAD ? __shfl(KT[b], half_src, 64)              \
+                                   : __shfl_xor(KT[b], G / 2, 64);            \
                     KT[b] = 0;                                                \
                 }                                                             \
             }                                                                 \

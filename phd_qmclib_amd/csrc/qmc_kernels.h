@@ -38,14 +38,14 @@ evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
     double z[P], F[P], ei[P], E, wf;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
     }
     eval_walker<G, P, PAD, true, true, ZC, R>(m, z, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         if (i < m.n) {
             if (a.ith) a.ith[w * m.n + i] = ei[p];
             if (a.drift) a.drift[w * m.n + i] = F[p];
@@ -82,14 +82,14 @@ prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
     double z[P], F[P], ei[P], E, wf;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
     }
     eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         if (i < m.n) a.drift[w * m.n + i] = F[p];
     }
     if (gl == 0) a.energy[w] = E;
@@ -152,7 +152,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     double mine = -1.0;       // >= 0 only in the lane that holds particle 0
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         const double zp = (i < n) ? a.pos[wr * n + i] : 0.0;
         labn[p] = (i < n) ? (int)a.label[wr * n + i] : i;
         const unsigned li = (unsigned)labn[p];
@@ -184,7 +184,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // well enough: a particle moves a few per cent of the spacing per step)
     if (!forced && (a.step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(zn, labn, gl, a.step / QMC_RESORT_EVERY, n, m.L,
-                          m.half_L);
+                          m.half_L, lanes_in_use<G, PAD>(m));
     double F[P], ei[P], e_new, wf_new;
     eval_walker<G, P, PAD, true, false, ZC, R>(m, zn, gl, lds, F, ei, e_new,
                                                wf_new);
@@ -227,7 +227,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     if (acc) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            int i = gl + G * p;
+            int i = lane_particle<G, PAD>(m, gl, p);
             if (i < n && !forced) {
                 a.pos[w * n + i] = zn[p];
                 a.label[w * n + i] = (unsigned short)labn[p];
@@ -239,7 +239,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     if (!LEAN && a.ser_pos) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            int i = gl + G * p;
+            int i = lane_particle<G, PAD>(m, gl, p);
             // series in the original particle order (a rejected move leaves
             // pos / label as they were: read them back)
             if (i < n) {
@@ -326,7 +326,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     int lab[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         double zz = 0.0;
         lab[p] = i;
         if (i < n) {
@@ -358,11 +358,11 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     }
     if ((step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(z, lab, gl, step / QMC_RESORT_EVERY, n, m.L,
-                          m.half_L);
+                          m.half_L, lanes_in_use<G, PAD>(m));
     // positions and labels leave now: not live across the pair sum
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         if (active && i < n) {
             a.cpos[s * n + i] = z[p];
             a.clabel[s * n + i] = (unsigned short)lab[p];
@@ -374,7 +374,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = gl + G * p;
+        int i = lane_particle<G, PAD>(m, gl, p);
         if (i < n) a.cdrift[s * n + i] = F[p];
     }
     if (gl == 0) {

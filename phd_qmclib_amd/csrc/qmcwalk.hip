@@ -533,6 +533,9 @@ static int engine_create_impl(const qmc_model_params *model, int device,
         return fail("qmc_engine_create: boson_number must be in [1, 512]");
     }
     build_dev_model(*model, e->dm);
+    // lanes of a group the rotation runs over: all of them when the model
+    // fills the shape, else the smallest even number that holds it
+    e->dm.ge = e->pad ? 2 * ((e->dm.n + 2 * e->P - 1) / (2 * e->P)) : e->G;
     // domain of the short-range kernel (qmc_device.h pair_core): the matching
     // conditions of mrbp_qmc/model.py:340-392 give phi = k2 r_off in (0, pi/2)
     // and k2 rm in (0, pi/2) for every repulsive model
