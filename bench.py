@@ -575,6 +575,12 @@ def cpu_baseline(args, spec, n, move_spread):
 
 # ------------------------------------------------------------------- main ---
 def run_rank(args):
+    # stdout carries ONE JSON line and nothing else: libraries that print to
+    # file descriptor 1 (RCCL's version banner at communicator creation) go
+    # to stderr for the lifetime of the rank
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -646,7 +652,8 @@ def run_rank(args):
             }
             m['vmc'].close()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
     if use_pg:
         dist.destroy_process_group()
 

@@ -8,6 +8,11 @@
 
 static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 
+// Minimum waves per SIMD asked of the register allocator: the N <= 64 shape
+// needs 66 VGPRs left to itself (7 waves); held to 64 it spills one double and
+// runs 8 waves, +1.5 % on the VMC step (profiles/r02_ab_variants.txt).
+#define QMC_LB_WAVES , ((G == 64 && P == 1) ? 8 : 1)
+
 // odd-even transposition passes (resort_step) run every this many steps
 #ifndef QMC_RESORT_EVERY
 #define QMC_RESORT_EVERY 4
@@ -22,7 +27,7 @@ struct EvalArgs {
 };
 
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
 evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the
@@ -66,7 +71,7 @@ struct PrepArgs {
 };
 
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
 prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the
@@ -128,7 +133,7 @@ struct VmcArgs {
 // only); the full variant adds the test-only tape replay, the Gaussian
 // proposal and the per-step series.
 template <int G, int P, bool PAD, bool ZC, bool LEAN, typename R = double>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
 vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 {
     const DevModel &m = *mp;
@@ -299,7 +304,7 @@ struct EvolveArgs {
 // Drift-diffusion + local energy of every child walker
 // (qmc_base/jastrow/dmc.py:758-825, 892-942).
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
 dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the

@@ -130,13 +130,19 @@ class DistributedDmc:
     """
 
     def __init__(self, ensemble, num_particles: int, device,
-                 rebalance_every: int = 32, imbalance_tol: float = 0.02):
+                 rebalance_every: int = 32, imbalance_tol: float = 0.02,
+                 force_collectives: bool = False):
+        """`force_collectives` issues the per-step all-reduce even in a group
+        of one rank (tests: the RCCL call and its stream ordering run on a
+        single GPU; a one-rank all-reduce is the identity)."""
         self.ens = ensemble
         self.n = int(num_particles)
         self.device = torch.device(device)
         self.rank, self.world = _world()
         self.rebalance_every = int(rebalance_every)
         self.imbalance_tol = float(imbalance_tol)
+        self._collect = self.world > 1 or (
+            force_collectives and dist.is_available() and dist.is_initialized())
         self._check_stream()
         self.sums = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.steps_done = 0
@@ -169,7 +175,7 @@ class DistributedDmc:
     def step(self):
         """One global time step, fully enqueued (no host synchronisation)."""
         self.ens.step_local(self._ptr(self.sums))
-        if self.world > 1:
+        if self._collect:
             dist.all_reduce(self.sums)          # 16 bytes, in place
         self.ens.step_finish(self._ptr(self.sums))
         self.steps_done += 1
@@ -206,7 +212,7 @@ class DistributedDmc:
                 out.append(None)
                 continue
             view = _wrap_f64(ptr, cnt, self.device)
-            if self.world > 1:
+            if self._collect:
                 dist.all_reduce(view)           # in place, engine's stream
             out.append(view.cpu().numpy().reshape(shape).copy())
         return out[0], out[1]

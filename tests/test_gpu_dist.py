@@ -210,3 +210,48 @@ def test_two_shards_one_population():
     assert np.allclose(got, want, rtol=1e-9, atol=1e-7)
     for h in (a, b, eng):
         h.close()
+
+
+def test_rccl_all_reduce_is_ordered_with_the_engine_stream():
+    """One-rank RCCL group on this GPU: the 16-byte all-reduce really runs
+    between step_local and step_finish of every step (force_collectives), on a
+    side stream the engine shares with torch.  A one-rank all-reduce is the
+    identity, so the series must equal the plain block run bit for bit; if the
+    collective were not ordered with the kernels (the engine used to
+    launch on a private stream) E_ref would be computed from stale sums."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from phd_qmclib_amd.dist import DistributedDmc
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}',
+                            rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            eng = ModelEngine(box(64).cfc_spec, stream=side.cuda_stream)
+            pos = 64 * np.random.RandomState(2).random_sample((4000, 64))
+            a = DmcEnsemble(eng, 1e-3, 4608, 4000, 0.5, rng_seed=4)
+            b = DmcEnsemble(eng, 1e-3, 4608, 4000, 0.5, rng_seed=4,
+                            external_reduce=True)
+            b.set_estimators(num_modes=6)
+            a.set_state(pos)
+            b.set_state(pos)
+            sa = a.run_block(40)
+            dd = DistributedDmc(b, 64, 'cuda', rebalance_every=8,
+                                force_collectives=True)
+            assert dd._collect
+            sb, ssf, _ = dd.run_block(40, estimators=True)
+            assert np.array_equal(sa.num_walkers, sb.num_walkers)
+            assert np.array_equal(sa.energy, sb.energy)
+            assert np.array_equal(sa.ref_energy, sb.ref_energy)
+            assert ssf.shape == (40, 6, 3) and ssf[-1, 1, 0] > 0
+            assert dd.global_counts() == [int(sb.num_walkers[-1])]
+            a.close(); b.close(); eng.close()
+    finally:
+        dist.destroy_process_group()
