@@ -11,6 +11,8 @@ static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 // Minimum waves per SIMD asked of the register allocator: the N <= 64 shape
 // needs 66 VGPRs left to itself (7 waves); held to 64 it spills one double and
 // runs 8 waves, +1.5 % on the VMC step (profiles/r02_ab_variants.txt).
+// (The N <= 128 shape held to 80 registers for 6 waves spills 56-140 bytes per
+// lane and loses 10-15 %.)
 #define QMC_LB_WAVES , ((G == 64 && P == 1) ? 8 : 1)
 
 // odd-even transposition passes (resort_step) run every this many steps
