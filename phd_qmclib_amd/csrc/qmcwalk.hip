@@ -332,6 +332,9 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
         d.m_k2 = -d.k2;
     }
     d.sin_rm = (d.rm >= d.half_L) ? 1.0 : sin(QMC_PI * d.rm / d.L);
+#ifdef QMC_ABLATION     // timing experiments (tools/build_variant.sh): wrong physics
+    if (const char *env = getenv("QMCWALK_ABL_SINRM")) d.sin_rm = atof(env);
+#endif
     // sin(pi r / L) is flat near r = L/2: classify from positions there
     d.zclass = d.rm > 0.45 * d.L;
     double pi_L = QMC_PI / d.L;
