@@ -235,6 +235,60 @@ __device__ __forceinline__ void resort_step(double (&z)[P], int (&lab)[P],
     }
 }
 
+// One walker per wavefront, one particle per lane (N <= 64): the lanes hold the
+// particles in ASCENDING position, not merely in cyclic order -- the place where
+// the positions wrap from L back to 0 stays at the lane-index seam (lane ge-1
+// -> lane 0).  The shifted second copy of the pair tables (pair_core1) relies
+// on it for speed (never for correctness): with the wrap point anywhere else,
+// 2k lanes of rotation step k leave the fast case.  Two pieces keep the order: an odd-even transposition pass on plain
+// positions that never exchanges across the seam, and `anchor_seam`, which
+// notices a particle that crossed the box boundary (it now sits at the wrong
+// end of the lanes) and rotates the whole row by one lane.
+template <int G>
+__device__ __forceinline__ void resort_linear(double &z, int &lab, int gl,
+                                              unsigned parity, int ge)
+{
+    const int lane = threadIdx.x & 63, base = lane - gl;
+    const int pg = (parity & 1u) ? ((gl & 1) ? gl + 1 : gl - 1) : (gl ^ 1);
+    const bool has = gl < ge && pg >= 0 && pg < ge;
+    const int src = base + (has ? pg : gl);
+    const double zp = __shfl(z, src, 64);
+    const int lp = __shfl(lab, src, 64);
+    // the lower lane of a pair keeps the smaller position
+    const bool take = has && ((gl < pg) ? zp < z : zp > z);
+    if (take) { z = zp; lab = lp; }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// (G = 64: the row is the wavefront, the test is scalar and the rotation a
+// wave-uniform branch that is almost never taken.)
+__device__ __forceinline__ void anchor_seam(double &z, int &lab,
+                                            int ge /* lanes holding particles */)
+{
+    const int lane = threadIdx.x & 63;
+    const double z0 = readlane_f64(z, 0), zl = readlane_f64(z, ge - 1);
+    if (zl < z0) {
+        const double z1 = readlane_f64(z, 1), zl1 = readlane_f64(z, ge - 2);
+        int src = lane;
+        if (zl < z1) {
+            // the last lane's particle left through z = L and is now the
+            // smallest: everybody moves one lane up, it takes lane 0
+            if (lane < ge) src = lane == 0 ? ge - 1 : lane - 1;
+        } else if (z0 > zl1) {
+            // the first lane's particle left through z = 0: the other way
+            if (lane < ge) src = lane == ge - 1 ? 0 : lane + 1;
+        }
+        z = __shfl(z, src, 64);
+        lab = __shfl(lab, src, 64);
+    }
+}
+
 // Per-particle table entry kept in registers by the owner and published to LDS.
 // R is the arithmetic type of the pair loop: double, or float for the
 // reduced-precision variant (the reference's `jit_fastmath` knob,
@@ -604,6 +658,10 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 // costs occupancy through LDS (P = 8: 128 KB per block, one wave per SIMD), so
 // the table is stored once and the rotated index is masked (one v_and per
 // partner table, i.e. per 2-8 pairs).
+#ifndef QMC_LINEAR_ORDER
+#define QMC_LINEAR_ORDER 1
+#endif
+
 // Tile-sweep knobs of the N = 512 shape (BASELINE.json configs[4]: "LDS
 // tile-size sweep"; tools/tile_sweep.sh builds the variants): own particles per
 // rotation pass (the register tile: 64 * QMC_PA8 particles) and copies of the
@@ -649,9 +707,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     const int n = m.n;
     const int ge = lanes_in_use<G, PAD>(m);   // lanes the rotation runs over
     // one-case form with a shifted second copy of the tables (pair_core1)
-    // (float pair loop only: in double the four-case form below measured
-    // 1.3 % faster, in float this one 2.3 % -- profiles/r02_ab_variants.txt)
-    constexpr bool ROTCOPY = (P == 1) && (DUP == 2) && !ZCLASS && !RD;
+    // (one particle per lane; in double only where the kernels keep the lanes
+    // in ascending position, i.e. one walker per wavefront: LINEAR_ORDER)
+    constexpr bool ROTCOPY = (P == 1) && (DUP == 2) && !ZCLASS &&
+                             (!RD || (G == 64 && QMC_LINEAR_ORDER));
     // four-case short-range form while the own tables fit (see pair_core4)
     constexpr bool FOURCASE = (P <= 2) && !ROTCOPY;
     PTabT<R> t[PA];

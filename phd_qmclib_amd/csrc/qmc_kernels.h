@@ -13,7 +13,10 @@ static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 // runs 8 waves, +1.5 % on the VMC step (profiles/r02_ab_variants.txt).
 // (The N <= 128 shape held to 80 registers for 6 waves spills 56-140 bytes per
 // lane and loses 10-15 %.)
-#define QMC_LB_WAVES , ((G == 64 && P == 1) ? 8 : 1)
+#ifndef QMC_LB_P1
+#define QMC_LB_P1 8
+#endif
+#define QMC_LB_WAVES , ((G == 64 && P == 1) ? QMC_LB_P1 : 1)
 
 // odd-even transposition passes (resort_step) run every this many steps
 #ifndef QMC_RESORT_EVERY
@@ -189,7 +192,16 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     QMC_SECTION("resort");
     // (one odd-even pass every QMC_RESORT_EVERY steps keeps the lanes sorted
     // well enough: a particle moves a few per cent of the spacing per step)
-    if (!forced && (a.step % QMC_RESORT_EVERY) == 0)
+    if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
+        // ascending order, wrap point anchored at the lane seam (qmc_device.h)
+        // (one particle per lane: lanes 0 .. n-1 hold them)
+        if (!forced) {
+            anchor_seam(zn[0], labn[0], n);
+            if ((a.step % QMC_RESORT_EVERY) == 0)
+                resort_linear<G>(zn[0], labn[0], gl,
+                                 a.step / QMC_RESORT_EVERY, n);
+        }
+    } else if (!forced && (a.step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(zn, labn, gl, a.step / QMC_RESORT_EVERY, n, m.L,
                           m.half_L, lanes_in_use<G, PAD>(m));
     double F[P], ei[P], e_new, wf_new;
@@ -363,7 +375,11 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         }
         z[p] = zz;
     }
-    if ((step % QMC_RESORT_EVERY) == 0)
+    if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
+        anchor_seam(z[0], lab[0], n);
+        if ((step % QMC_RESORT_EVERY) == 0)
+            resort_linear<G>(z[0], lab[0], gl, step / QMC_RESORT_EVERY, n);
+    } else if ((step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(z, lab, gl, step / QMC_RESORT_EVERY, n, m.L,
                           m.half_L, lanes_in_use<G, PAD>(m));
     // positions and labels leave now: not live across the pair sum
