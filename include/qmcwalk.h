@@ -116,6 +116,14 @@ int qmc_model_one_body_table_info(const qmc_model_params *model,
                                   int32_t *rows_well, int32_t *rows_barrier,
                                   double *max_err);
 
+/* Diagnostic (no GPU needed): the row table of the pair-function angles
+ * (sin / cos of pi z / L and of k2 z, mrbp_qmc/model.py:466-531) the kernels
+ * would use for this model: rows over [0, L) (0 = the angles are evaluated by
+ * polynomial `sincos` directly) and the worst absolute deviation of the
+ * kernels' row + angle-addition arithmetic from long-double sin / cos. */
+int qmc_model_trig_table_info(const qmc_model_params *model, int32_t *rows,
+                              double *max_err);
+
 /* ---- engine: model constants on one device --------------------------- */
 int qmc_engine_create(const qmc_model_params *model, int device, void *stream,
                       qmc_engine **out);

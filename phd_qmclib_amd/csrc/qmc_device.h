@@ -81,6 +81,15 @@ struct DevModel {
     double ob_invh1;       // m1 / z_a
     double ob_invh2;       // m2 / z_b   (>= ob_invh1)
     double ob_shift2;      // m1 / ob_invh2 - z_a
+    // pair-table angles by row + angle addition (trig_tab): tg_rows rows of
+    // width tg_h = L / tg_rows over [0, L), each {sin, cos(pi z_r / L), sin,
+    // cos(k2 z_r)} at the row centre z_r; null when the model's angles span too
+    // much for a cache-resident table
+    const double *trig_table;
+    int tg_rows;
+    double tg_inv_h, tg_h;
+    double tg_a1, tg_b1;   // pi/L, -(pi/L) h/2:  angle offset = a dz + b
+    double tg_a2, tg_b2;   // k2,   -k2 h/2
 };
 
 // One-body table row (128 bytes, one cache line per particle): degree OB_DEG
@@ -302,6 +311,39 @@ struct PTabT {
 };
 typedef PTabT<double> PTab;
 
+// sin/cos of the two pair-table angles of a particle at z from the row table:
+// theta = theta_row + delta with |delta| <= QMC_TRIG_DMAX (host: build_trig_table),
+// sin/cos(delta) by their first terms (truncation < 1e-17), the row values
+// correctly rounded.  29 vector instructions against 68 for two polynomial
+// `sincos_halfpi`.  Returns false -- for the whole wavefront -- if any lane's z
+// lies outside [0, L) (the batch evaluation takes positions as they come); the
+// caller then evaluates directly.
+typedef const __attribute__((address_space(1))) double *qmc_gptr;
+
+__device__ __forceinline__ void sincos_small(double d, double &s, double &c)
+{
+    const double d2 = d * d;
+    s = fma(d * d2, fma(d2, sconst(1.0 / 120.0), sconst(-1.0 / 6.0)), d);
+    c = fma(d2, fma(d2, sconst(1.0 / 24.0), -0.5), 1.0);
+}
+
+__device__ __forceinline__ bool trig_tab(const DevModel &m, double z, PTab &ta)
+{
+    const int r = (int)(z * m.tg_inv_h);          // truncation
+    if (__ballot((unsigned)r >= (unsigned)m.tg_rows)) return false;
+    const double dz = fma(-(double)r, m.tg_h, z); // [0, h): r h is exact
+    const qmc_gptr row = (qmc_gptr)m.trig_table + 4u * (unsigned)r;
+    const double S1 = row[0], C1 = row[1], S2 = row[2], C2 = row[3];
+    double sd, cd;
+    sincos_small(fma(dz, m.tg_a1, m.tg_b1), sd, cd);
+    ta.s = fma(S1, cd, C1 * sd);
+    ta.c = fma(C1, cd, -(S1 * sd));
+    sincos_small(fma(dz, m.tg_a2, m.tg_b2), sd, cd);
+    ta.su = fma(S2, cd, C2 * sd);
+    ta.cu = fma(C2, cd, -(S2 * sd));
+    return true;
+}
+
 // One-body factor (mrbp_qmc/model.py:404-464) and lattice potential (:533-551).
 // ldz = f1'/f1; kin_pot = -f1''/f1 + ldz^2 + V(z); the factor itself is
 // f1 * exp(-xoff) > 0 (the barrier's cosh x is returned as (e^{2x} + 1) / 2
@@ -359,8 +401,6 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
 // pair tables occupy registers.
 // `logf1` is log of the factor itself (the direct path returns the factor and
 // a split-off exponent).
-typedef const __attribute__((address_space(1))) double *qmc_gptr;
-
 template <bool WF>
 __device__ __forceinline__ void one_body_tab(const DevModel &m, double z,
                                              double &ldz, double &logf1,
@@ -787,8 +827,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         __builtin_amdgcn_sched_barrier(0);
         if (!m.is_ideal) {
             PTab ta;
-            sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
-            sincos_halfpi(z[a] * m.k2_2pi, ta.su, ta.cu);
+            if (!(m.trig_table && trig_tab(m, z[a], ta))) {
+                sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
+                sincos_halfpi(z[a] * m.k2_2pi, ta.su, ta.cu);
+            }
             if (NPASS == 1) {
                 t[a % PA].s = (R)ta.s; t[a % PA].c = (R)ta.c;
                 t[a % PA].su = (R)ta.su; t[a % PA].cu = (R)ta.cu;

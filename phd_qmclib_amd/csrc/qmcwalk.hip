@@ -51,6 +51,7 @@ struct qmc_engine {
     DevModel dm;
     DevModel *dm_dev = nullptr;
     double *ob_table_dev = nullptr;     // one-body table rows (or null)
+    double *trig_table_dev = nullptr;   // pair-angle row table (or null)
     qmc_model_params mp;
     int G = 64, P = 1;
     bool pad = false;
@@ -499,6 +500,46 @@ static void build_ob_table(const DevModel &d, std::vector<double> &tab,
     tab.insert(tab.end(), reg[0].begin(), reg[0].begin() + OB_ROW);
 }
 
+// Row table of the pair-table angles (qmc_device.h trig_tab): the smallest
+// power-of-two row count that keeps both angle offsets inside QMC_TRIG_DMAX,
+// nothing if that takes more than QMC_TRIG_MAX_ROWS rows (128 KB).
+#define QMC_TRIG_DMAX 4.0e-3
+#define QMC_TRIG_MAX_ROWS 4096
+#ifndef QMC_TRIG_TABLE
+#define QMC_TRIG_TABLE 1       // 0: build variant without it (A/B runs)
+#endif
+static void build_trig_table(DevModel &d, std::vector<double> &tab)
+{
+    tab.clear();
+    d.trig_table = nullptr;
+    d.tg_rows = 0;
+    if (d.is_ideal || !(d.L > 0.0) || !QMC_TRIG_TABLE) return;
+    const double span = fmax(QMC_PI, fabs(d.k2) * d.L);
+    int rows = 256;
+    while (rows <= QMC_TRIG_MAX_ROWS && span / (2.0 * rows) > QMC_TRIG_DMAX)
+        rows *= 2;
+    if (rows > QMC_TRIG_MAX_ROWS) return;
+    const double h = d.L / rows;
+    tab.resize((size_t)rows * 4);
+    const long double pil = 3.141592653589793238462643383279502884L;
+    for (int r = 0; r < rows; ++r) {
+        const long double zr = ((long double)r + 0.5L) * (long double)h;
+        const long double a1 = pil * zr / (long double)d.L;
+        const long double a2 = (long double)d.k2 * zr;
+        tab[4 * r + 0] = (double)sinl(a1);
+        tab[4 * r + 1] = (double)cosl(a1);
+        tab[4 * r + 2] = (double)sinl(a2);
+        tab[4 * r + 3] = (double)cosl(a2);
+    }
+    d.tg_rows = rows;
+    d.tg_h = h;
+    d.tg_inv_h = (double)rows / d.L;
+    d.tg_a1 = QMC_PI / d.L;
+    d.tg_b1 = -d.tg_a1 * 0.5 * h;
+    d.tg_a2 = d.k2;
+    d.tg_b2 = -d.k2 * 0.5 * h;
+}
+
 // Diagnostic, no GPU needed: the table a model would get.
 extern "C" int qmc_model_one_body_table_info(const qmc_model_params *model,
                                              int32_t *rows_well,
@@ -577,10 +618,73 @@ static int engine_create_impl(const qmc_model_params *model, int device,
             d.ob_shift2 = (double)m1 / d.ob_invh2 - d.z_a;
         }
     }
+    {
+        std::vector<double> tab;
+        build_trig_table(e->dm, tab);
+        if (!tab.empty()) {
+            HIP_TRY(hipMalloc((void **)&e->trig_table_dev,
+                              tab.size() * sizeof(double)));
+            HIP_TRY(hipMemcpy(e->trig_table_dev, tab.data(),
+                              tab.size() * sizeof(double),
+                              hipMemcpyHostToDevice));
+            e->dm.trig_table = e->trig_table_dev;
+        }
+    }
     HIP_TRY(hipMalloc((void **)&e->dm_dev, sizeof(DevModel)));
     HIP_TRY(hipMemcpy(e->dm_dev, &e->dm, sizeof(DevModel),
                       hipMemcpyHostToDevice));
     *out = e;
+    return 0;
+}
+
+// Diagnostic, no GPU needed: the pair-angle row table a model would get and
+// the worst deviation of trig_tab's arithmetic (restated here on the host,
+// operation for operation) from long-double sin / cos over [0, L).
+static void trig_small_host(double d, double &s, double &c)
+{
+    const double d2 = d * d;
+    s = fma(d * d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), d);
+    c = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+}
+
+extern "C" int qmc_model_trig_table_info(const qmc_model_params *model,
+                                         int32_t *rows, double *max_err)
+{
+    if (!model) return fail("qmc_model_trig_table_info: null argument");
+    DevModel d;
+    build_dev_model(*model, d);
+    std::vector<double> tab;
+    build_trig_table(d, tab);
+    if (rows) *rows = d.tg_rows;
+    double worst = 0.0;
+    if (d.tg_rows) {
+        const long double pil = 3.141592653589793238462643383279502884L;
+        const int samples = 7;            // per row, edges included
+        for (int r = 0; r < d.tg_rows; ++r) {
+            for (int j = 0; j <= samples; ++j) {
+                double z = ((double)r + (double)j / samples) * d.tg_h;
+                if (j == samples) z = nextafter(z, 0.0);
+                const int rr = (int)(z * d.tg_inv_h);
+                if (rr < 0 || rr >= d.tg_rows) continue;   // device falls back
+                const double dz = fma(-(double)rr, d.tg_h, z);
+                const double *row = &tab[4 * (size_t)rr];
+                double sd, cd, got[4];
+                trig_small_host(fma(dz, d.tg_a1, d.tg_b1), sd, cd);
+                got[0] = fma(row[0], cd, row[1] * sd);
+                got[1] = fma(row[1], cd, -(row[0] * sd));
+                trig_small_host(fma(dz, d.tg_a2, d.tg_b2), sd, cd);
+                got[2] = fma(row[2], cd, row[3] * sd);
+                got[3] = fma(row[3], cd, -(row[2] * sd));
+                const long double a1 = pil * (long double)z / (long double)d.L;
+                const long double a2 = (long double)d.k2 * (long double)z;
+                const long double ref[4] = { sinl(a1), cosl(a1), sinl(a2),
+                                             cosl(a2) };
+                for (int k = 0; k < 4; ++k)
+                    worst = fmax(worst, (double)fabsl((long double)got[k] - ref[k]));
+            }
+        }
+    }
+    if (max_err) *max_err = worst;
     return 0;
 }
 
@@ -668,6 +772,7 @@ extern "C" void qmc_engine_destroy(qmc_engine *e)
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->dm_dev) hipFree(e->dm_dev);
     if (e->ob_table_dev) hipFree(e->ob_table_dev);
+    if (e->trig_table_dev) hipFree(e->trig_table_dev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }

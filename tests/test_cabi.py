@@ -40,3 +40,52 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.QmcError, match='no CPU fallback'):
         _lib.load()
+
+
+# ---- the model tables the kernels read, built and checked on the host ------
+def _models():
+    from math import pi
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    out = []
+    for n, cut in ((16, 0.25), (64, 0.25), (100, 0.1), (128, 0.25), (512, 0.05)):
+        out.append(Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                        interaction_strength=2, boson_number=n,
+                        supercell_size=n, tbf_contact_cutoff=cut * n))
+    out.append(Spec(lattice_depth=20., lattice_ratio=0.5,
+                    interaction_strength=10., boson_number=24,
+                    supercell_size=24, tbf_contact_cutoff=3.0))
+    return out
+
+
+def test_trig_row_table_matches_long_double():
+    """qmc_device.h trig_tab (row + angle addition) restated on the host by
+    the library's diagnostic: at most an ulp from long-double sin / cos."""
+    import ctypes as C
+    from phd_qmclib_amd import _lib
+    from phd_qmclib_amd.engine import model_params_struct
+    lib = _lib.load()
+    seen_rows = set()
+    for spec in _models():
+        mp = model_params_struct(spec.cfc_spec)
+        rows, err = C.c_int32(0), C.c_double(0)
+        assert lib.qmc_model_trig_table_info(C.byref(mp), C.byref(rows),
+                                             C.byref(err)) == 0
+        assert rows.value >= 256, 'every test model is tabulated'
+        assert rows.value & (rows.value - 1) == 0
+        assert err.value < 3.5e-16, (spec.boson_number, rows.value, err.value)
+        seen_rows.add(rows.value)
+    assert len(seen_rows) >= 1
+
+
+def test_one_body_table_matches_closed_forms():
+    import ctypes as C
+    from phd_qmclib_amd import _lib
+    from phd_qmclib_amd.engine import model_params_struct
+    lib = _lib.load()
+    for spec in _models():
+        mp = model_params_struct(spec.cfc_spec)
+        m1, m2, err = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        assert lib.qmc_model_one_body_table_info(
+            C.byref(mp), C.byref(m1), C.byref(m2), C.byref(err)) == 0
+        assert m1.value > 0 and m2.value > 0
+        assert err.value < 5e-15
