@@ -194,6 +194,45 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
+// The same over a whole wavefront on the matrix cores: a v_mfma_f64_16x16x4
+// contracts over k = lane >> 4, so A = the lanes' values against B = ones
+// leaves r_i = the sum of the four lanes with lane & 15 = i in row i; a lane
+// holds rows (lane >> 4) + 4 reg, adds its four and feeds the partial back as
+// A: every element of the second product is the total.  Two sums share the
+// second product (rows 0-7 carry one, rows 8-15 the other).  Against the
+// butterfly (12 ds_bpermute + 6 adds per sum, the LDS pipe being the kernel's
+// second-busiest resource) this is 3 vector adds and no LDS traffic.
+#ifndef QMC_MFMA_SUM
+#define QMC_MFMA_SUM 1
+#endif
+typedef double qmc_v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_partial_mfma(double v)
+{
+    const qmc_v4d zero = {0.0, 0.0, 0.0, 0.0};
+    const qmc_v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, zero, 0, 0, 0);
+    return (d[0] + d[1]) + (d[2] + d[3]);
+}
+
+__device__ __forceinline__ double wave_sum_mfma(double v)
+{
+    const qmc_v4d zero = {0.0, 0.0, 0.0, 0.0};
+    const qmc_v4d t = __builtin_amdgcn_mfma_f64_16x16x4f64(
+        wave_partial_mfma(v), 1.0, zero, 0, 0, 0);
+    return t[0];
+}
+
+__device__ __forceinline__ void wave_sum2_mfma(double a, double b, double &sa,
+                                               double &sb)
+{
+    const qmc_v4d zero = {0.0, 0.0, 0.0, 0.0};
+    const double pa = wave_partial_mfma(a), pb = wave_partial_mfma(b);
+    const qmc_v4d t = __builtin_amdgcn_mfma_f64_16x16x4f64(
+        (threadIdx.x & 8) ? pb : pa, 1.0, zero, 0, 0, 0);
+    sa = t[0];          // rows 0-3
+    sb = t[2];          // rows 8-11
+}
+
 // Lane order = position order.  Bosons are identical, so which lane holds which
 // particle is free; when the lanes of a group hold the particles in (cyclic)
 // position order, the lanes met at rotation step k all sit at about the same
@@ -266,6 +305,28 @@ __device__ __forceinline__ void resort_linear(double &z, int &lab, int gl,
     // the lower lane of a pair keeps the smaller position
     const bool take = has && ((gl < pg) ? zp < z : zp > z);
     if (take) { z = zp; lab = lp; }
+}
+
+// Travelling sums of the rotation loop move one lane per step.  On a whole
+// wavefront that is `v_mov_b32_dpp wave_ror:1` (two per double) instead of two
+// ds_bpermute_b32 through the LDS pipe, which the loop's table reads need:
+// -3 % on the VMC and DMC steps at N = 64 (profiles/r02_ab_variants.txt).
+#ifndef QMC_T_DPP
+#define QMC_T_DPP 1
+#endif
+// every lane takes the value of the lane below, lane 0 that of lane 63
+__device__ __forceinline__ double wave_ror1(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float wave_ror1(float v)
+{
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false);
+    return __int_as_float(x);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -949,6 +1010,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         }
 
         // ---- k = 1 .. G/2: rotate over partner lanes ----
+        constexpr bool ROT_DPP = QMC_T_DPP && (G == 64) && !PAD;
         const int lane = threadIdx.x & 63;
         // the lane below in the ring of the ge lanes in use
         const int src = lane - gl + (PAD ? (gl == 0 ? ge - 1 : gl - 1)
@@ -1020,8 +1082,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             if (!(LAST)) {                                                    \
                 _Pragma("unroll")                                             \
                 for (int b = 0; b < P; ++b) {                                 \
-                    T[b] = __shfl(T[b], src, 64);                             \
-                    if (ITH) KT[b] = __shfl(KT[b], src, 64);                  \
+                    T[b] = ROT_DPP ? wave_ror1(T[b]) : __shfl(T[b], src, 64); \
+                    if (ITH) KT[b] = ROT_DPP ? wave_ror1(KT[b])               \
+                                             : __shfl(KT[b], src, 64);        \
                 }                                                             \
             }                                                                 \
             /* P = 1: 16 factors between folds, each >= sin(pi rm / L) or   \
@@ -1097,16 +1160,22 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         for (int a = 0; a < P; ++a)
             if (ok[a]) e_lane -= F[a] * F[a];
     }
-    E = group_sum<G>(e_lane);
+    // (one walker per wavefront: the sums over the lanes run on the matrix
+    // cores, the energy's together with log|psi|'s further down)
+    constexpr bool MSUM = QMC_MFMA_SUM && (G == 64);
+    if (!MSUM) E = group_sum<G>(e_lane);
+    else if (!WF) E = wave_sum_mfma(e_lane);
+    double e_consts = 0.0;
     if (WAVE_COUNT && !ITH && nb_counted) {
         // one-body region constants of the n particles, nb_wave in a barrier
-        E += (double)(n - nb_wave) * m.e0 +
-             (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
+        e_consts += (double)(n - nb_wave) * m.e0 +
+                    (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
     }
     if (WAVE_COUNT && !ITH && !m.is_ideal) {
         int nl_wave = n * (n - 1) / 2 - ns_wave;
-        E += 2.0 * (m.k2sq * (double)ns_wave + m.b_long * (double)nl_wave);
+        e_consts += 2.0 * (m.k2sq * (double)ns_wave + m.b_long * (double)nl_wave);
     }
+    if (!(MSUM && WF)) E += e_consts;
     if (WF) {
         const double LN2 = 0.693147180559945309417;
         // prodL holds every pair's |Y|, prodS the short ones (cos > 0):
@@ -1118,7 +1187,12 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                            m.beta * (double)(expL - expS)) -
                     xoff_sum;
         if (!WAVE_COUNT) lw += (double)nshort * m.log_am;
-        logwf = group_sum<G>(lw);
+        if (MSUM) {
+            wave_sum2_mfma(e_lane, lw, E, logwf);
+            E += e_consts;
+        } else {
+            logwf = group_sum<G>(lw);
+        }
         if (WAVE_COUNT) logwf += (double)ns_wave * m.log_am;
     }
 #undef QMC_FOLD
