@@ -311,22 +311,31 @@ __device__ __forceinline__ void resort_linear(double &z, int &lab, int gl,
 // wavefront that is `v_mov_b32_dpp wave_ror:1` (two per double) instead of two
 // ds_bpermute_b32 through the LDS pipe, which the loop's table reads need:
 // -3 % on the VMC and DMC steps at N = 64 (profiles/r02_ab_variants.txt).
+// (Adding the partner's share into an LDS row with ds_add_f64 instead -- no
+// travelling sum at all, 3 vector instructions fewer per step -- measured the
+// same time with two table-shaped rows and 3.5 % more with one masked row.)
 #ifndef QMC_T_DPP
 #define QMC_T_DPP 1
 #endif
-// every lane takes the value of the lane below, lane 0 that of lane 63
-__device__ __forceinline__ double wave_ror1(double v)
+// every lane takes the value of the lane below it in its group, the first lane
+// that of the last (groups of 64: wave_ror:1; of 16: row_ror:1)
+template <int G>
+__device__ __forceinline__ int group_ror1_b32(int x)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
+    static_assert(G == 64 || G == 16, "a DPP rotation exists for 16 and 64 lanes");
+    if (G == 64) return __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(x, x, 0x121, 0xf, 0xf, false);
 }
-__device__ __forceinline__ float wave_ror1(float v)
+template <int G>
+__device__ __forceinline__ double group_ror1(double v)
 {
-    int x = __float_as_int(v);
-    x = __builtin_amdgcn_update_dpp(x, x, 0x13C, 0xf, 0xf, false);
-    return __int_as_float(x);
+    return __hiloint2double(group_ror1_b32<G>(__double2hiint(v)),
+                            group_ror1_b32<G>(__double2loint(v)));
+}
+template <int G>
+__device__ __forceinline__ float group_ror1(float v)
+{
+    return __int_as_float(group_ror1_b32<G>(__float_as_int(v)));
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
@@ -1010,7 +1019,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         }
 
         // ---- k = 1 .. G/2: rotate over partner lanes ----
-        constexpr bool ROT_DPP = QMC_T_DPP && (G == 64) && !PAD;
+        constexpr bool ROT_DPP = QMC_T_DPP && (G == 64 || G == 16) && !PAD;
         const int lane = threadIdx.x & 63;
         // the lane below in the ring of the ge lanes in use
         const int src = lane - gl + (PAD ? (gl == 0 ? ge - 1 : gl - 1)
@@ -1082,9 +1091,13 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             if (!(LAST)) {                                                    \
                 _Pragma("unroll")                                             \
                 for (int b = 0; b < P; ++b) {                                 \
-                    T[b] = ROT_DPP ? wave_ror1(T[b]) : __shfl(T[b], src, 64); \
-                    if (ITH) KT[b] = ROT_DPP ? wave_ror1(KT[b])               \
-                                             : __shfl(KT[b], src, 64);        \
+                    if constexpr (ROT_DPP) {                                  \
+                        T[b] = group_ror1<G>(T[b]);                           \
+                        if (ITH) KT[b] = group_ror1<G>(KT[b]);                \
+                    } else {                                                  \
+                        T[b] = __shfl(T[b], src, 64);                         \
+                        if (ITH) KT[b] = __shfl(KT[b], src, 64);              \
+                    }                                                         \
                 }                                                             \
             }                                                                 \
             /* P = 1: 16 factors between folds, each >= sin(pi rm / L) or   \
