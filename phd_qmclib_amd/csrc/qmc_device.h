@@ -59,6 +59,13 @@ struct DevModel {
     double cth, sth;       // cos(k2 L), |sin(k2 L)|
     int sth_sign;          // sign bit of sin(k2 L) (0 or 0x80000000)
     double sth_signed;     // sin(k2 L)
+    // leading all-short rotation steps (eval_walker, one particle per lane): a
+    // pair seen through the shifted tables is short, unwrapped and ordered iff
+    //   sp_xlo < X < sp_xhi and Y > 0,   X = -k2 sin(theta), Y = cos(theta),
+    // theta = k2 D' - phi; that identifies D' uniquely when k2 L < pi (sp_ok)
+    double sp_xlo, sp_xhi;
+    double sp_cos;         // cos(k2 rm)
+    int sp_ok;
     // short-range variants (pair_core4): angles c_v added to k2 z_own,
     // v = (no wrap, d > 0), (no wrap, d < 0), (D > L/2), (D < -L/2)
     double var_cos[4], var_sin[4];
@@ -532,6 +539,8 @@ struct PairConstsT {
     int sth_sign;
     R sth_signed, k2sphi;
     R k2sq, inv_beta, b_long;
+    R sp_xlo, sp_xhi, sp_cos;
+    int sp_ok;
 };
 typedef PairConstsT<double> PairConsts;
 
@@ -547,6 +556,8 @@ __device__ __forceinline__ PairConstsT<R> load_pair_consts(const DevModel &m)
     c.m_k2 = (R)m.m_k2;
     c.sth_signed = (R)m.sth_signed; c.k2sphi = (R)m.k2sphi;
     c.k2sq = (R)m.k2sq; c.inv_beta = (R)m.inv_beta; c.b_long = (R)m.b_long;
+    c.sp_xlo = (R)m.sp_xlo; c.sp_xhi = (R)m.sp_xhi; c.sp_ok = m.sp_ok;
+    c.sp_cos = (R)m.sp_cos;
     asm volatile("" : "+v"(c.v_sth), "+v"(c.v_k2sphi));
     return c;
 }
@@ -770,6 +781,9 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 // partner table, i.e. per 2-8 pairs).
 #ifndef QMC_LINEAR_ORDER
 #define QMC_LINEAR_ORDER 1
+#endif
+#ifndef QMC_LEAD_SHORT
+#define QMC_LEAD_SHORT 1
 #endif
 
 // Tile-sweep knobs of the N = 512 shape (BASELINE.json configs[4]: "LDS
@@ -1120,7 +1134,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             /* (kept rolled: unrolled, the scheduler hoists the LDS reads of \
                every copy and the kernel loses half its occupancy: -8 %) */  \
             QMC_SECTION("rotation_loop_body");                                \
-            for (int k = 1; k < ge / 2; ++k)                                  \
+            for (int k = ((H) == 0 ? k_first : 1); k < ge / 2; ++k)           \
                 QMC_KSTEP(H, k, false)                                        \
             QMC_SECTION("rotation_last_step");                                \
             QMC_KSTEP(H, ge / 2, true)                                        \
@@ -1138,6 +1152,97 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 }                                                             \
             }                                                                 \
         }
+        // One walker per wavefront in ascending order: the first rotation
+        // steps (partners a few lanes away) are short-range pairs for EVERY
+        // lane -- about the first third of the steps at rm = L/4 -- and need
+        // only the partner's k2-table, no classification by sin(pi d / L) and
+        // no exec-masked region.  k = 1, 2 (neighbours: between two passes of
+        // the transposition sort some are out of order, which sends the whole
+        // wave through the generic branch of pair_core1 in four steps of five)
+        // use the form that is exact for either sign of the separation: 10
+        // vector instructions + the division against ~40.  From k = 3 the pairs
+        // are the single case of the shifted tables: X, Y of the one-case form
+        // and three compares that decide exactly whether the pair is short,
+        // unwrapped and ordered (DevModel.sp_*), 18 instructions per step
+        // against 24.  The first step where some lane says no is redone by the
+        // general loop, which takes over from there.
+        int k_first = 1;
+        constexpr bool LEAD_SHORT = QMC_LEAD_SHORT && ROTCOPY && (G == 64) &&
+                                    !PAD && (P == 1);
+        if constexpr (LEAD_SHORT) {
+            if (pc.sp_ok) {
+                R Q1 = 0, P1 = 1;          // tallies of these steps
+                int e1 = 0;
+                bool lead = true;
+#define QMC_LEAD_TAIL(X, Y)                                                   \
+                {                                                             \
+                    const R q = pair_div(X, Y);                               \
+                    ns_wave += 64;                                            \
+                    Fr[0] += q;                                               \
+                    T[0] -= q;                                                \
+                    Q1 = q_fma(q, q, Q1);                                     \
+                    if (WF) P1 *= Y;                                          \
+                    if (ITH) {                                                \
+                        const R kk = q_fma(q, q, pc.k2sq);                    \
+                        Kown[0] += kk;                                        \
+                        KT[0] += kk;                                          \
+                    }                                                         \
+                    T[0] = group_ror1<G>(T[0]);                               \
+                    if (ITH) KT[0] = group_ror1<G>(KT[0]);                    \
+                }
+                QMC_SECTION("leading_neighbour_steps");
+                {
+                    const R osu = lSU[G + gl], ocu = lCU[G + gl];
+                    for (; k_first <= 2; ++k_first) {
+                        const int idx = gl + G - k_first;
+                        const R bsu = lSU[idx], bcu = lCU[idx];
+                        const R Su = osu * bcu - ocu * bsu;   // sin(k2 D')
+                        const R Cu = ocu * bcu + osu * bsu;   // cos(k2 D')
+                        // |k2 D'| < pi: |D'| < rm iff cos(k2 D') > cos(k2 rm)
+                        if (__builtin_amdgcn_ballot_w64(Cu > pc.sp_cos) != ~0ull) {
+                            lead = false;
+                            break;
+                        }
+                        const R t2 = q_copysign(pc.k2sphi, Su);
+                        const R Xs = q_fma(pc.m_k2cphi, Su, Cu * t2);
+                        const R Ys = q_fma(q_abs(Su), pc.sphi, Cu * pc.cphi);
+                        QMC_LEAD_TAIL(Xs, Ys)
+                    }
+                }
+                QMC_SECTION("leading_short_steps");
+                if (lead) {
+                    const OwnShort1T<R> o = os1[0];
+                    for (; k_first < G / 2; ++k_first) {
+                        const int idx = gl + G - k_first;
+                        const R bsu = lSU[idx], bcu = lCU[idx];
+                        const R Xs = o.ks0 * bcu - o.kc0 * bsu;
+                        const R Ys = o.c0 * bcu + o.s0 * bsu;
+                        // (one ballot per compare: each is the compare's own
+                        // mask; all 64 lanes are active here)
+                        const unsigned long long fast =
+                            __builtin_amdgcn_ballot_w64(Xs > pc.sp_xlo) &
+                            __builtin_amdgcn_ballot_w64(Xs < pc.sp_xhi) &
+                            __builtin_amdgcn_ballot_w64(Ys > (R)0);
+                        if (fast != ~0ull) break;
+                        QMC_LEAD_TAIL(Xs, Ys)
+                        if (WF && (k_first & 15) == 0) {
+                            asm volatile("");   // a branch, not selects
+                            QMC_FOLD(P1, e1);
+                        }
+                    }
+                }
+#undef QMC_LEAD_TAIL
+                // these pairs belong to the tallies of all pairs and of the
+                // short ones
+                Qall += Q1; Qs += Q1;
+                if (WF) {
+                    QMC_FOLD(P1, e1);
+                    prodS *= P1; prodL *= P1;
+                    expS += e1; expL += e1;
+                }
+            }
+        }
+        QMC_SECTION("rotation");
         QMC_PASS(0)
         QMC_PASS(1)
         QMC_PASS(2)

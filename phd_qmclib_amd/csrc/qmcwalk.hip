@@ -323,6 +323,13 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.sth = fabs(sin(th));
     d.sth_sign = sin(th) < 0.0 ? (int)0x80000000u : 0;
     d.sth_signed = sin(th);
+    // leading all-short steps (qmc_device.h): theta = k2 D' - phi must identify
+    // D' within a window of two box lengths
+    d.sp_ok = (!d.is_ideal && th > 0.0 && th < QMC_PI - 1e-9 &&
+               d.rm < d.half_L) ? 1 : 0;
+    d.sp_xlo = -d.k2 * sin(d.k2 * d.rm - phi);
+    d.sp_xhi = d.k2 * sin(phi);
+    d.sp_cos = cos(d.k2 * d.rm);
     {
         // angles added to k2 z_own for the four short-range cases
         const double ang[4] = { -phi, phi, phi - th, th - phi };
