@@ -172,21 +172,38 @@ __device__ __forceinline__ double wrap_box(double z, double L)
     return z;
 }
 
-// Particle held by (lane gl, register p) of a lane group, or n (= none).
-// A shape that fits the model exactly uses all G lanes: i = gl + G p.  A
-// padded shape (N < G P) uses only the first ge = 2 ceil(N / 2P) lanes of the
-// group, i = gl + ge p, and rotates over those: N = 100 on the (64, 2) shape
-// runs 25 rotation steps over 50 lanes instead of 32 over 64 (round 1 paid the
-// full shape: 4.7e11 pair evaluations/s at N = 100 against 8.0e11 at N = 128).
+// Slot (index into the walker's row of positions) held by (lane gl, register p)
+// of a lane group; >= n = none.
+// One walker per wavefront with several particles per lane (N > 64): a lane
+// holds P CONSECUTIVE slots, i = P gl + p.  The rows are kept in ascending
+// position, so the partner lane of rotation step k holds the particles about
+// P k places away -- all P^2 pairs of a lane at a step are at about the same
+// separation and the short-range branch is taken or skipped by whole
+// wavefronts.  (With slots strided over the lanes, i = gl + 64 p, every step
+// mixes near and far partners: N = 128 ran both branches in all 31 steps.)
+// Smaller groups: i = gl + G p.  A padded shape (N < G P) uses only the first
+// ge = 2 ceil(N / 2P) lanes of the group (strided: i = gl + ge p) and rotates
+// over those: N = 100 on the (64, 2) shape runs 25 rotation steps over 50 lanes
+// instead of 32 over 64 (round 1 paid the full shape: 4.7e11 pair evaluations/s
+// at N = 100 against 8.0e11 at N = 128).
+#ifndef QMC_INTERLEAVE
+#define QMC_INTERLEAVE 1
+#endif
+template <int G, int P>
+struct SlotMap {
+    static constexpr bool CONSECUTIVE = QMC_INTERLEAVE && (G == 64) && (P >= 2);
+};
+
 template <int G, bool PAD>
 __device__ __forceinline__ int lanes_in_use(const DevModel &m)
 {
     return PAD ? m.ge : G;
 }
 
-template <int G, bool PAD>
+template <int G, int P, bool PAD>
 __device__ __forceinline__ int lane_particle(const DevModel &m, int gl, int p)
 {
+    if (SlotMap<G, P>::CONSECUTIVE) return P * gl + p;
     if (!PAD) return gl + G * p;
     const int ge = m.ge;
     return gl < ge ? gl + ge * p : m.n;
@@ -374,6 +391,96 @@ __device__ __forceinline__ void anchor_seam(double &z, int &lab,
         lab = __shfl(lab, src, 64);
     }
 }
+
+// The same for several particles per lane (consecutive slots, SlotMap): the
+// sequence is the slot index i = P gl + a.  Even phase: pairs (i, i + 1) with i
+// even, both in one lane (P is even) -- no lane traffic; odd phase: the pairs
+// inside the lane and the one across to the next lane.
+template <int P>
+__device__ __forceinline__ void order_pair(double &za, int &la, double &zb,
+                                           int &lb, bool valid)
+{
+    const bool sw = valid && zb < za;
+    const double t = za; const int u = la;
+    za = sw ? zb : za; la = sw ? lb : la;
+    zb = sw ? t : zb; lb = sw ? u : lb;
+}
+
+template <int P>
+__device__ __forceinline__ void resort_linear_rows(double (&z)[P], int (&lab)[P],
+                                                   int gl, unsigned parity, int n)
+{
+    static_assert(P % 2 == 0, "consecutive slots: an even number per lane");
+    const int i0 = P * gl;
+    if (!(parity & 1u)) {
+#pragma unroll
+        for (int a = 0; a + 1 < P; a += 2)
+            order_pair<P>(z[a], lab[a], z[a + 1], lab[a + 1], i0 + a + 1 < n);
+    } else {
+        const int lane = threadIdx.x & 63;
+        // the neighbours' end slots as they are now
+        const double up = __shfl(z[0], lane + 1, 64);
+        const int lup = __shfl(lab[0], lane + 1, 64);
+        const double dn = __shfl(z[P - 1], lane - 1, 64);
+        const int ldn = __shfl(lab[P - 1], lane - 1, 64);
+        const double top = z[P - 1], bot = z[0];
+#pragma unroll
+        for (int a = 1; a + 1 < P; a += 2)
+            order_pair<P>(z[a], lab[a], z[a + 1], lab[a + 1], i0 + a + 1 < n);
+        // (slot i0 + P - 1, slot i0 + P) and (slot i0 - 1, slot i0): both
+        // sides of a pair see the same two values
+        if (gl < 63 && i0 + P < n && up < top) { z[P - 1] = up; lab[P - 1] = lup; }
+        if (gl > 0 && i0 < n && dn > bot) { z[0] = dn; lab[0] = ldn; }
+    }
+}
+
+// register r (wave-uniform, runtime) of a lane's row
+template <int P, typename T>
+__device__ __forceinline__ T row_reg(const T (&v)[P], int r)
+{
+    T x = v[0];
+#pragma unroll
+    for (int a = 1; a < P; ++a) x = (r == a) ? v[a] : x;
+    return x;
+}
+
+template <int P>
+__device__ __forceinline__ void anchor_seam_rows(double (&z)[P], int (&lab)[P],
+                                                 int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int ln = (n - 1) / P, rn = (n - 1) % P;      // the last slot
+    const double z0 = readlane_f64(z[0], 0);
+    const double zl = readlane_f64(row_reg<P>(z, rn), ln);
+    if (zl < z0) {
+        const double z1 = readlane_f64(z[1], 0);
+        const int ln2 = (n - 2) / P, rn2 = (n - 2) % P;
+        const double zl1 = readlane_f64(row_reg<P>(z, rn2), ln2);
+        if (zl < z1) {
+            // the last slot's particle left through z = L and is now the
+            // smallest: every particle moves one slot up, it takes slot 0
+            const int labl = __builtin_amdgcn_readlane(row_reg<P>(lab, rn), ln);
+            double zin = __shfl(z[P - 1], lane - 1, 64);
+            int lin = __shfl(lab[P - 1], lane - 1, 64);
+            if (lane == 0) { zin = zl; lin = labl; }
+#pragma unroll
+            for (int a = P - 1; a >= 1; --a) { z[a] = z[a - 1]; lab[a] = lab[a - 1]; }
+            z[0] = zin; lab[0] = lin;
+        } else if (z0 > zl1) {
+            // the first slot's particle left through z = 0: the other way
+            const int lab0 = __builtin_amdgcn_readlane(lab[0], 0);
+            const double zin = __shfl(z[0], lane + 1, 64);
+            const int lin = __shfl(lab[0], lane + 1, 64);
+#pragma unroll
+            for (int a = 0; a + 1 < P; ++a) { z[a] = z[a + 1]; lab[a] = lab[a + 1]; }
+            z[P - 1] = zin; lab[P - 1] = lin;
+#pragma unroll
+            for (int a = 0; a < P; ++a)
+                if (lane == ln && a == rn) { z[a] = z0; lab[a] = lab0; }
+        }
+    }
+}
+
 
 // Per-particle table entry kept in registers by the owner and published to LDS.
 // R is the arithmetic type of the pair loop: double, or float for the
@@ -865,7 +972,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     QMC_SECTION("tables+onebody");
 #pragma unroll
     for (int a = 0; a < P; ++a) {
-        ok[a] = !PAD || lane_particle<G, PAD>(m, gl, a) < n;
+        ok[a] = !PAD || lane_particle<G, P, PAD>(m, gl, a) < n;
         F[a] = 0.0; T[a] = 0; Kown[a] = 0; KT[a] = 0;
         if (ITH) kin1[a] = 0.0;
         // the one-body factor first: its table rows (or its transcendental
@@ -1061,7 +1168,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 pb.su = lSU[idx]; pb.cu = lCU[idx];                           \
                 const R pz = ZCLASS ? lZ[idx] : (R)0;                         \
                 const bool pok = !PAD ||                                      \
-                    (gl < ge && pl + ge * b < n);                             \
+                    (gl < ge && lane_particle<G, P, PAD>(m, pl, b) < n);      \
                 _Pragma("unroll")                                             \
                 for (int a = 0; a < PA; ++a) {                                \
                     constexpr int ao_base = (H) * PA;                         \
@@ -1101,6 +1208,14 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                    of different partners (it trades the occupancy away       \
                    for it: 282 registers instead of ~180 at P = 8) */        \
                 if (P >= 4) __builtin_amdgcn_sched_barrier(0);                \
+                /* float products: the P pairs of one partner are all near   \
+                   or all far (consecutive slots); P^2 factors of a few     \
+                   per cent would leave the float range before the fold at  \
+                   the end of the step */                                    \
+                if (WF && !RD && P >= 4) {                                    \
+                    QMC_FOLD(prodS, expS);                                    \
+                    QMC_FOLD(prodL, expL);                                    \
+                }                                                             \
             }                                                                 \
             if (!(LAST)) {                                                    \
                 _Pragma("unroll")                                             \

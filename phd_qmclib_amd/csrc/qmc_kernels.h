@@ -48,14 +48,14 @@ evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
     double z[P], F[P], ei[P], E, wf;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
     }
     eval_walker<G, P, PAD, true, true, ZC, R>(m, z, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         if (i < m.n) {
             if (a.ith) a.ith[w * m.n + i] = ei[p];
             if (a.drift) a.drift[w * m.n + i] = F[p];
@@ -92,14 +92,14 @@ prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
     double z[P], F[P], ei[P], E, wf;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
     }
     eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         if (i < m.n) a.drift[w * m.n + i] = F[p];
     }
     if (gl == 0) a.energy[w] = E;
@@ -162,7 +162,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     double mine = -1.0;       // >= 0 only in the lane that holds particle 0
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         const double zp = (i < n) ? a.pos[wr * n + i] : 0.0;
         labn[p] = (i < n) ? (int)a.label[wr * n + i] : i;
         const unsigned li = (unsigned)labn[p];
@@ -200,6 +200,12 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             if ((a.step % QMC_RESORT_EVERY) == 0)
                 resort_linear<G>(zn[0], labn[0], gl,
                                  a.step / QMC_RESORT_EVERY, n);
+        }
+    } else if constexpr (SlotMap<G, P>::CONSECUTIVE && QMC_LINEAR_ORDER) {
+        if (!forced) {
+            anchor_seam_rows<P>(zn, labn, n);
+            if ((a.step % QMC_RESORT_EVERY) == 0)
+                resort_linear_rows<P>(zn, labn, gl, a.step / QMC_RESORT_EVERY, n);
         }
     } else if (!forced && (a.step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(zn, labn, gl, a.step / QMC_RESORT_EVERY, n, m.L,
@@ -246,7 +252,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     if (acc) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            int i = lane_particle<G, PAD>(m, gl, p);
+            int i = lane_particle<G, P, PAD>(m, gl, p);
             if (i < n && !forced) {
                 a.pos[w * n + i] = zn[p];
                 a.label[w * n + i] = (unsigned short)labn[p];
@@ -258,7 +264,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     if (!LEAN && a.ser_pos) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            int i = lane_particle<G, PAD>(m, gl, p);
+            int i = lane_particle<G, P, PAD>(m, gl, p);
             // series in the original particle order (a rejected move leaves
             // pos / label as they were: read them back)
             if (i < n) {
@@ -345,7 +351,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     int lab[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         double zz = 0.0;
         lab[p] = i;
         if (i < n) {
@@ -379,13 +385,17 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         anchor_seam(z[0], lab[0], n);
         if ((step % QMC_RESORT_EVERY) == 0)
             resort_linear<G>(z[0], lab[0], gl, step / QMC_RESORT_EVERY, n);
+    } else if constexpr (SlotMap<G, P>::CONSECUTIVE && QMC_LINEAR_ORDER) {
+        anchor_seam_rows<P>(z, lab, n);
+        if ((step % QMC_RESORT_EVERY) == 0)
+            resort_linear_rows<P>(z, lab, gl, step / QMC_RESORT_EVERY, n);
     } else if ((step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(z, lab, gl, step / QMC_RESORT_EVERY, n, m.L,
                           m.half_L, lanes_in_use<G, PAD>(m));
     // positions and labels leave now: not live across the pair sum
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         if (active && i < n) {
             a.cpos[s * n + i] = z[p];
             a.clabel[s * n + i] = (unsigned short)lab[p];
@@ -397,7 +407,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int i = lane_particle<G, PAD>(m, gl, p);
+        int i = lane_particle<G, P, PAD>(m, gl, p);
         if (i < n) a.cdrift[s * n + i] = F[p];
     }
     if (gl == 0) {
