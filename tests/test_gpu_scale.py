@@ -189,6 +189,48 @@ def test_large_shapes_trajectories_vs_oracle(oracle, n):
     eng.close()
 
 
+@pytest.mark.parametrize('n', [37, 64, 100, 128, 512])
+def test_long_trajectories_across_the_box_boundary(oracle, n):
+    """Lane order is kept ascending with the place where positions wrap from L
+    to 0 anchored at the end of the row (`anchor_seam`, `anchor_seam_rows`):
+    whenever a particle crosses the box boundary the whole row moves by one
+    slot.  Long chains with wide moves cross it many times; positions (handed
+    back in particle order through the labels), log|psi| and the carried energy
+    must still be the oracle's on the same Philox streams."""
+    from phd_qmclib_amd.engine import ModelEngine, VmcEnsemble
+    spec = box(n)
+    m = oracle.model_from_cfc(spec.cfc_spec)
+    eng = ModelEngine(spec.cfc_spec)
+    rng = np.random.RandomState(1000 + n)
+    W, ns, spread = 6, 60, 0.6
+    L = float(n)
+    pos0 = L * rng.random_sample((W, n))
+    v = VmcEnsemble(eng, W, spread, rng_seed=21)
+    v.set_state(pos0)
+    out = v.run_block(ns, series=True)
+    pos, wf, ec = v.get_state()
+    matched = crossings = 0
+    for c in range(W):
+        ch = oracle.VmcChain(m, pos0[c], spread, seed=21, chain=c)
+        stat, prev = [], np.mod(pos0[c], L)
+        for t in range(ns):
+            _, _, st, _ = ch.run(1)
+            stat.append(bool(st[0]))
+            cur = np.mod(ch.pos, L)
+            crossings += int((np.abs(cur - prev) > 0.5 * L).sum())
+            prev = cur
+        if np.array_equal(np.array(stat), out['move_stat'][:, c]):
+            matched += 1
+            assert np.allclose(np.mod(pos[c], L), np.mod(ch.pos, L),
+                               rtol=0, atol=1e-9), c
+            assert wf[c] == pytest.approx(float(ch.wf[0]), rel=1e-9, abs=1e-8)
+    # an accept decision can flip on a last-bit difference of log|psi|
+    assert matched >= W - 2
+    assert crossings >= 3, 'the chains did cross the boundary'
+    v.close()
+    eng.close()
+
+
 def test_random_specs_all_shapes_vs_oracle(oracle):
     """Differential test over random models at random sizes up to 512 (every
     lane-group shape, exact and padded, both pair classifiers): evaluate on
