@@ -189,7 +189,7 @@ def test_large_shapes_trajectories_vs_oracle(oracle, n):
     eng.close()
 
 
-@pytest.mark.parametrize('n', [37, 64, 100, 128, 512])
+@pytest.mark.parametrize('n', [37, 64, 100, 101, 128, 300, 512])
 def test_long_trajectories_across_the_box_boundary(oracle, n):
     """Lane order is kept ascending with the place where positions wrap from L
     to 0 anchored at the end of the row (`anchor_seam`, `anchor_seam_rows`):
