@@ -1395,7 +1395,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     }
     // (one walker per wavefront: the sums over the lanes run on the matrix
     // cores, the energy's together with log|psi|'s further down)
-    constexpr bool MSUM = QMC_MFMA_SUM && (G == 64);
+    // (one particle per lane only: with more, the accumulator registers of the
+    // matrix instruction cost the N = 128 DMC step a wave of occupancy, -5 %)
+    constexpr bool MSUM = QMC_MFMA_SUM && (G == 64) && (P == 1);
     if (!MSUM) E = group_sum<G>(e_lane);
     else if (!WF) E = wave_sum_mfma(e_lane);
     double e_consts = 0.0;
