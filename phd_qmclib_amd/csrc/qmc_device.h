@@ -669,6 +669,54 @@ __device__ __forceinline__ PairConstsT<R> load_pair_consts(const DevModel &m)
     return c;
 }
 
+// Short-range X, Y of a pair from the k2-tables of both particles, exact for
+// any order of the two and either side of the periodic wrap.
+template <typename R>
+__device__ __forceinline__ void short_generic(const PairConstsT<R> &m,
+                                              const PTabT<R> &a,
+                                              const PTabT<R> &b, R S,
+                                              bool wrapped, R &X, R &Y)
+{
+    R Su = a.su * b.cu - a.cu * b.su;   // sin(k2 (z_a - z_b))
+    R Cu = a.cu * b.cu + a.su * b.su;
+    if (wrapped) {
+        // keep this a real (exec-masked) branch: as selects it costs four
+        // v_cndmask on top of the arithmetic
+        asm volatile("");
+        // min image d = D - sgn(D) L; sgn(D) = sgn(S)
+        if constexpr (sizeof(R) == 8) {
+            // t = sin(k2 L) sgn(S): copysign on |sin(k2 L)|, then the sign
+            // of sin(k2 L) itself (k2 L is any angle) xor-ed into the high
+            // word
+            double t = __builtin_copysign(m.v_sth, S);
+            t = __hiloint2double(__double2hiint(t) ^ m.sth_sign,
+                                 __double2loint(t));
+            double ct, st;
+            const double cth = m.cth;
+            // in place, exactly four instructions (the compiler's
+            // two-address v_fmac form needs two extra 64-bit moves at the
+            // join)
+            asm("v_mul_f64 %[ct], %[cu], %[t]\n\t"
+                "v_mul_f64 %[st], %[su], %[t]\n\t"
+                "v_fma_f64 %[su], %[su], %[cth], -%[ct]\n\t"
+                "v_fma_f64 %[cu], %[cu], %[cth], %[st]"
+                : [su] "+v"(Su), [cu] "+v"(Cu), [ct] "=&v"(ct),
+                  [st] "=&v"(st)
+                : [t] "v"(t), [cth] "s"(cth));
+        } else {
+            const R t = q_copysign(m.sth_signed, S * m.sth_signed);
+            const R ns = Su * m.cth - Cu * t;
+            const R nc = Cu * m.cth + Su * t;
+            Su = ns; Cu = nc;
+        }
+    }
+    // now (Su, Cu) = sin/cos(k2 d), |k2 d| < pi/2, sgn(Su) = sgn(d):
+    //   -k2 tan(k2 r - phi) sgn(d) = X / Y with
+    R t2 = q_copysign(m.v_k2sphi, Su);
+    X = q_fma(m.m_k2cphi, Su, Cu * t2);
+    Y = q_fma(q_abs(Su), m.sphi, Cu * m.cphi);
+}
+
 // One pair, seen from the own particle (table `a`, long-range numerator
 // coefficients aks/akc = a_long * (sin, cos)) against partner table `b`.
 //   q       : contribution to the drift of the own particle (partner: -q)
@@ -698,44 +746,7 @@ __device__ __forceinline__ void pair_core(const PairConstsT<R> &m,
     // SGPR mask (later it costs a v_cndmask + v_cmp round trip)
     shortmask = __ballot(isshort);
     if (isshort) {
-        R Su = a.su * b.cu - a.cu * b.su;   // sin(k2 (z_a - z_b))
-        R Cu = a.cu * b.cu + a.su * b.su;
-        if (wrapped) {
-            // keep this a real (exec-masked) branch: as selects it costs four
-            // v_cndmask on top of the arithmetic
-            asm volatile("");
-            // min image d = D - sgn(D) L; sgn(D) = sgn(S)
-            if constexpr (sizeof(R) == 8) {
-                // t = sin(k2 L) sgn(S): copysign on |sin(k2 L)|, then the sign
-                // of sin(k2 L) itself (k2 L is any angle) xor-ed into the high
-                // word
-                double t = __builtin_copysign(m.v_sth, S);
-                t = __hiloint2double(__double2hiint(t) ^ m.sth_sign,
-                                     __double2loint(t));
-                double ct, st;
-                const double cth = m.cth;
-                // in place, exactly four instructions (the compiler's
-                // two-address v_fmac form needs two extra 64-bit moves at the
-                // join)
-                asm("v_mul_f64 %[ct], %[cu], %[t]\n\t"
-                    "v_mul_f64 %[st], %[su], %[t]\n\t"
-                    "v_fma_f64 %[su], %[su], %[cth], -%[ct]\n\t"
-                    "v_fma_f64 %[cu], %[cu], %[cth], %[st]"
-                    : [su] "+v"(Su), [cu] "+v"(Cu), [ct] "=&v"(ct),
-                      [st] "=&v"(st)
-                    : [t] "v"(t), [cth] "s"(cth));
-            } else {
-                const R t = q_copysign(m.sth_signed, S * m.sth_signed);
-                const R ns = Su * m.cth - Cu * t;
-                const R nc = Cu * m.cth + Su * t;
-                Su = ns; Cu = nc;
-            }
-        }
-        // now (Su, Cu) = sin/cos(k2 d), |k2 d| < pi/2, sgn(Su) = sgn(d):
-        //   -k2 tan(k2 r - phi) sgn(d) = X / Y with
-        R t2 = q_copysign(m.v_k2sphi, Su);
-        X = q_fma(m.m_k2cphi, Su, Cu * t2);
-        Y = q_fma(q_abs(Su), m.sphi, Cu * m.cphi);
+        short_generic<R>(m, a, b, S, wrapped, X, Y);
     }
     q = pair_div(X, Y);
     Yout = Y;
@@ -810,6 +821,61 @@ __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
 #undef QMC_CASE4
         X = m.m_k2 * xs;
         Y = ys;
+    }
+    q = pair_div(X, Y);
+    Yout = Y;
+}
+
+// Short-range pair, two-case form (two particles per lane, rows in ascending
+// order).  Of the four (wrap, sign) cases a sorted row meets two: the partner a
+// few places below (D in (0, L/2)) and, in the lanes whose partner index wraps,
+// the partner at the far end of the box (D in (-L, -L/2)).  The own particle
+// carries the angle tables of those two (8 registers instead of 32 for four, 8
+// instead of 16 instructions to build them); a pair in another case -- two
+// neighbours that passed each other since the last sort pass -- takes
+// `short_generic`.
+template <typename R>
+struct ShortTab2T {
+    R s0, c0;      // (no wrap, d > 0)
+    R s3, c3;      // (D < -L/2)
+};
+
+template <typename R>
+__device__ __forceinline__ void make_short_tab2(const DevModel &m, double su,
+                                                double cu, ShortTab2T<R> &st)
+{
+    st.s0 = (R)fma(su, m.var_cos[0], cu * m.var_sin[0]);
+    st.c0 = (R)fma(cu, m.var_cos[0], -(su * m.var_sin[0]));
+    st.s3 = (R)fma(su, m.var_cos[3], cu * m.var_sin[3]);
+    st.c3 = (R)fma(cu, m.var_cos[3], -(su * m.var_sin[3]));
+}
+
+template <typename R>
+__device__ __forceinline__ void pair_core2(const PairConstsT<R> &m,
+                                           const PTabT<R> &a,
+                                           const ShortTab2T<R> &sa, R aks,
+                                           R akc, const PTabT<R> &b, R &q,
+                                           R &Yout, bool &isshort,
+                                           unsigned long long &shortmask)
+{
+    R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
+    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R Y = S;
+    const bool wrapped = X < (R)0;   // |z_a - z_b| > L/2
+    const bool neg = S < (R)0;       // sgn(D) = sgn(sin(pi D / L))
+    isshort = q_abs(S) < m.sin_rm;   // min-image r < rm
+    shortmask = __ballot(isshort);
+    if (isshort) {
+        if (wrapped == neg) {
+            asm volatile("");
+            const R os = neg ? sa.s3 : sa.s0, oc = neg ? sa.c3 : sa.c0;
+            const R xs = os * b.cu - oc * b.su;
+            Y = oc * b.cu + os * b.su;
+            X = m.m_k2 * xs;
+        } else {
+            asm volatile("");
+            short_generic<R>(m, a, b, S, wrapped, X, Y);
+        }
     }
     q = pair_div(X, Y);
     Yout = Y;
@@ -892,6 +958,9 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 #ifndef QMC_LEAD_SHORT
 #define QMC_LEAD_SHORT 1
 #endif
+#ifndef QMC_TWOCASE
+#define QMC_TWOCASE 1
+#endif
 
 // Tile-sweep knobs of the N = 512 shape (BASELINE.json configs[4]: "LDS
 // tile-size sweep"; tools/tile_sweep.sh builds the variants): own particles per
@@ -942,11 +1011,15 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     // in ascending position, i.e. one walker per wavefront: LINEAR_ORDER)
     constexpr bool ROTCOPY = (P == 1) && (DUP == 2) && !ZCLASS &&
                              (!RD || (G == 64 && QMC_LINEAR_ORDER));
+    // two particles per lane in ascending rows: two-case form (pair_core2)
+    constexpr bool TWOCASE = QMC_TWOCASE && (P == 2) && (G == 64) && !ZCLASS &&
+                             QMC_LINEAR_ORDER && SlotMap<G, P>::CONSECUTIVE;
     // four-case short-range form while the own tables fit (see pair_core4)
-    constexpr bool FOURCASE = (P <= 2) && !ROTCOPY;
+    constexpr bool FOURCASE = (P <= 2) && !ROTCOPY && !TWOCASE;
     PTabT<R> t[PA];
     ShortTabT<R> st4[FOURCASE ? PA : 1];
     OwnShort1T<R> os1[ROTCOPY ? PA : 1];
+    ShortTab2T<R> st2[TWOCASE ? PA : 1];
     R aks[PA], akc[PA];      // a_long * (sin, cos)(pi z / L)
     const R a_long_r = (R)m.a_long;
     bool ok[P];
@@ -1028,6 +1101,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 aks[a % PA] = (R)(m.a_long * ta.s);
                 akc[a % PA] = (R)(m.a_long * ta.c);
                 if (FOURCASE) make_short_tab<R>(m, ta.su, ta.cu, st4[a % PA]);
+                if (TWOCASE) make_short_tab2<R>(m, ta.su, ta.cu, st2[a % PA]);
                 if (ROTCOPY) {
                     OwnShort1T<R> &o = os1[a % PA];
                     const double s0 = fma(ta.su, m.cphi, -(ta.cu * m.sphi));
@@ -1180,6 +1254,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                                       lSU[a * DUP * G + ge + gl],             \
                                       lCU[a * DUP * G + ge + gl], q, Y, sh,   \
                                       shm);                                   \
+                    else if (TWOCASE)                                         \
+                        pair_core2<R>(pc, t[a], st2[TWOCASE ? a : 0], aks[a], \
+                                      akc[a], pb, q, Y, sh, shm);             \
                     else if (FOURCASE)                                        \
                         pair_core4<ZCLASS, R>(pc, t[a],                       \
                                               st4[FOURCASE ? a : 0], aks[a],  \
