@@ -723,11 +723,16 @@ __device__ __forceinline__ void short_generic(const PairConstsT<R> &m,
 //   Yout    : the denominator = the factor |f2| up to constants
 //             (short: cos(k2 r - phi); long: sin(pi d / L), signed)
 //   isshort : r < rm
+//   live    : both particles exist.  The idle slots of a padded shape hold
+//             z = 0; classified like real particles they are "short" whenever
+//             their partner is near the box boundary and pull whole wavefronts
+//             through the short-range branches (N = 100: 15 % of the step).
 template <bool ZCLASS, typename R>
 __device__ __forceinline__ void pair_core(const PairConstsT<R> &m,
                                           const PTabT<R> &a, R aks, R akc,
-                                          R za, const PTabT<R> &b, R zb, R &q,
-                                          R &Yout, bool &isshort,
+                                          R za, const PTabT<R> &b, R zb,
+                                          bool live, R &q, R &Yout,
+                                          bool &isshort,
                                           unsigned long long &shortmask)
 {
     R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
@@ -737,10 +742,10 @@ __device__ __forceinline__ void pair_core(const PairConstsT<R> &m,
     if (ZCLASS) {
         R aD = q_abs(za - zb);
         wrapped = aD > m.half_L;
-        isshort = (aD < m.rm) | (aD > m.L_minus_rm);
+        isshort = live & ((aD < m.rm) | (aD > m.L_minus_rm));
     } else {
         wrapped = X < (R)0;               // |z_a - z_b| > L/2
-        isshort = q_abs(S) < m.sin_rm;    // min-image r < rm
+        isshort = live & (q_abs(S) < m.sin_rm);   // min-image r < rm
     }
     // taken here, in the block of the compare, the ballot is the compare's own
     // SGPR mask (later it costs a v_cndmask + v_cmp round trip)
@@ -784,7 +789,8 @@ __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
                                            const PTabT<R> &a,
                                            const ShortTabT<R> &sa, R aks,
                                            R akc, R za, const PTabT<R> &b,
-                                           R zb, R &q, R &Yout, bool &isshort,
+                                           R zb, bool live, R &q, R &Yout,
+                                           bool &isshort,
                                            unsigned long long &shortmask)
 {
     R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
@@ -796,11 +802,11 @@ __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
         const R aD = q_abs(D);
         wrapped = aD > m.half_L;
         neg = D < (R)0;
-        isshort = (aD < m.rm) | (aD > m.L_minus_rm);
+        isshort = live & ((aD < m.rm) | (aD > m.L_minus_rm));
     } else {
         wrapped = X < (R)0;               // |z_a - z_b| > L/2
         neg = S < (R)0;                   // sgn(D) = sgn(sin(pi D / L))
-        isshort = q_abs(S) < m.sin_rm;    // min-image r < rm
+        isshort = live & (q_abs(S) < m.sin_rm);   // min-image r < rm
     }
     shortmask = __ballot(isshort);
     if (isshort) {
@@ -854,8 +860,8 @@ template <typename R>
 __device__ __forceinline__ void pair_core2(const PairConstsT<R> &m,
                                            const PTabT<R> &a,
                                            const ShortTab2T<R> &sa, R aks,
-                                           R akc, const PTabT<R> &b, R &q,
-                                           R &Yout, bool &isshort,
+                                           R akc, const PTabT<R> &b, bool live,
+                                           R &q, R &Yout, bool &isshort,
                                            unsigned long long &shortmask)
 {
     R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
@@ -863,7 +869,10 @@ __device__ __forceinline__ void pair_core2(const PairConstsT<R> &m,
     R Y = S;
     const bool wrapped = X < (R)0;   // |z_a - z_b| > L/2
     const bool neg = S < (R)0;       // sgn(D) = sgn(sin(pi D / L))
-    isshort = q_abs(S) < m.sin_rm;   // min-image r < rm
+    // min-image r < rm.  (`live` = both particles exist: the idle slots of a
+    // padded shape hold z = 0 and would otherwise pull whole wavefronts into
+    // the generic branch whenever their partner is near the box boundary)
+    isshort = live & (q_abs(S) < m.sin_rm);
     shortmask = __ballot(isshort);
     if (isshort) {
         if (wrapped == neg) {
@@ -904,13 +913,14 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
                                            R ac, const OwnShort1T<R> &o,
                                            R aks, R akc, const PTabT<R> &b,
                                            bool lower, R own_su, R own_cu,
-                                           R &q, R &Yout, bool &isshort,
+                                           bool live, R &q, R &Yout,
+                                           bool &isshort,
                                            unsigned long long &shortmask)
 {
     R S = as * b.c - ac * b.s;       // sin(pi (z_a - z_b') / L)
     R X = akc * b.c + aks * b.s;     // a_long * cos(...)
     R Y = S;
-    isshort = q_abs(S) < m.sin_rm;   // min-image r < rm
+    isshort = live & (q_abs(S) < m.sin_rm);   // min-image r < rm
     shortmask = __ballot(isshort);
     if (isshort) {
         if ((S > (R)0) & (X > (R)0)) {
@@ -1195,10 +1205,13 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 R q, Y; bool sh; unsigned long long shm;
                 if (FOURCASE)
                     pair_core4<ZCLASS, R>(pc, ta, st4[a % PA], aksa, akca,
-                                          (R)z[a], tb, (R)z[b], q, Y, sh, shm);
+                                          (R)z[a], tb, (R)z[b],
+                                          !PAD || (ok[a] && ok[b]), q, Y, sh,
+                                          shm);
                 else
                     pair_core<ZCLASS, R>(pc, ta, aksa, akca, (R)z[a], tb,
-                                         (R)z[b], q, Y, sh, shm);
+                                         (R)z[b], !PAD || (ok[a] && ok[b]), q,
+                                         Y, sh, shm);
                 if (WAVE_COUNT)
                     ns_wave += __popcll(shm);
                 if (!PAD || (ok[a] && ok[b])) {
@@ -1247,30 +1260,31 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 for (int a = 0; a < PA; ++a) {                                \
                     constexpr int ao_base = (H) * PA;                         \
                     R q, Y; bool sh; unsigned long long shm;                 \
+                    const bool live = !PAD || (ok[ao_base + a] && pok);       \
                     if (ROTCOPY)                                              \
                         pair_core1<R>(pc, t[a].s, t[a].c,                     \
                                       os1[ROTCOPY ? a : 0], aks[a], akc[a],   \
                                       pb, gl < (k),                           \
                                       lSU[a * DUP * G + ge + gl],             \
-                                      lCU[a * DUP * G + ge + gl], q, Y, sh,   \
-                                      shm);                                   \
+                                      lCU[a * DUP * G + ge + gl], live, q, Y, \
+                                      sh, shm);                               \
                     else if (TWOCASE)                                         \
                         pair_core2<R>(pc, t[a], st2[TWOCASE ? a : 0], aks[a], \
-                                      akc[a], pb, q, Y, sh, shm);             \
+                                      akc[a], pb, live, q, Y, sh, shm);       \
                     else if (FOURCASE)                                        \
                         pair_core4<ZCLASS, R>(pc, t[a],                       \
                                               st4[FOURCASE ? a : 0], aks[a],  \
                                               akc[a], (R)z[ao_base + a], pb,  \
-                                              pz, q, Y, sh, shm);             \
+                                              pz, live, q, Y, sh, shm);       \
                     else                                                      \
                         pair_core<ZCLASS, R>(pc, t[a], aks[a], akc[a],        \
-                                             (R)z[ao_base + a], pb, pz, q, Y, \
-                                             sh, shm);                        \
+                                             (R)z[ao_base + a], pb, pz, live, \
+                                             q, Y, sh, shm);                  \
                     /* G = 64: the lower half of the lanes is bits 0..31 */   \
                     if (WAVE_COUNT)                                           \
                         ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \
                                                    : shm);                    \
-                    if (!PAD || (ok[ao_base + a] && pok)) {                   \
+                    if (live) {                                               \
                         Fr[ao_base + a] += q;                                 \
                         if (!(LAST)) T[b] -= q;                               \
                         if (!(LAST) || count_pair) { QMC_TALLY(q, Y, sh); }   \
