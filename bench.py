@@ -122,12 +122,33 @@ def launch_ranks(args, argv):
         procs.append(subprocess.Popen(
             [sys.executable, os.path.abspath(__file__)] + list(argv),
             env=env, stdout=subprocess.PIPE if r == 0 else None))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    # a rank that dies leaves the others waiting in a collective: stop them
+    # (the processes started here, by handle) instead of waiting for the
+    # process group's timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    out = procs[0].stdout.read()
+    if rc == 0:
+        sys.stdout.write(out.decode())
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(f'bench.py: a rank exited with status {rc}\n')
     return rc
 
 

@@ -4,6 +4,8 @@ handle is the oracle-backed look-alike of tests/_dist_worker.py and the
 process group is gloo; it exists so that `bench.py --gpus 2` (rank spawning,
 rendezvous, the sharded-DMC host logic and the JSON line) can be exercised
 without a GPU.  bench.py never selects it by itself."""
+import os
+
 import numpy as np
 import torch
 
@@ -18,6 +20,9 @@ class Backend:
     has_vmc = False
 
     def __init__(self, local_rank):
+        # (a rank that dies before it joins the process group: launcher test)
+        if os.environ.get('QMC_STANDIN_FAIL_RANK') == str(local_rank):
+            raise SystemExit(7)
         self.local_rank = local_rank
         self.device = torch.device('cpu')
 

@@ -52,3 +52,19 @@ def test_bench_refuses_world_size_mismatch():
                    'QMC_BENCH_BACKEND': 'tests._bench_standin'})
     assert r.returncode != 0
     assert 'WORLD_SIZE' in r.stderr
+
+
+@pytest.mark.timeout(120)
+def test_launcher_stops_the_other_ranks_when_one_dies(oracle):
+    """Rank 1 exits before the rendezvous: rank 0 would wait for it until the
+    process group's timeout; the launcher ends it and reports the failure."""
+    import time
+    t0 = time.time()
+    r = run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1',
+                   '--c4-bosons', '8', '--c4-walkers', '48', '--no-checks'],
+                  {'QMC_BENCH_BACKEND': 'tests._bench_standin',
+                   'QMC_STANDIN_FAIL_RANK': '1'}, timeout=100)
+    assert r.returncode == 7
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert 'a rank exited with status 7' in r.stderr
+    assert time.time() - t0 < 90
