@@ -301,9 +301,10 @@ def test_dmc_estimators_through_sampling_and_proc():
     assert 14.0 < dn.mean.sum() <= 16.0 + 1e-9
 
 
-def test_vmc_to_dmc_handoff_on_device():
+def test_vmc_to_dmc_handoff_on_device(oracle):
     """VMC chains seed the DMC population without a host round trip
-    (the pipeline of tests/mrbp_qmc/test_dmc.py:76-83)."""
+    (the pipeline of tests/mrbp_qmc/test_dmc.py:76-83); the population that
+    results is the oracle's built from the same configurations."""
     from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
     spec = box(16)
     eng = ModelEngine(spec.cfc_spec)
@@ -322,7 +323,17 @@ def test_vmc_to_dmc_handoff_on_device():
     assert np.array_equal(sa.confs[:, 0], sb.confs[:, 0])
     assert np.allclose(sa.confs[:, 1], sb.confs[:, 1], rtol=1e-11, atol=1e-11)
     assert sa.ref_energy == pytest.approx(sb.ref_energy, rel=1e-13)
-    assert np.allclose(a.run_block(5).energy, b.run_block(5).energy, rtol=1e-10)
+    ser_a, ser_b = a.run_block(5), b.run_block(5)
+    assert np.allclose(ser_a.energy, ser_b.energy, rtol=1e-10)
+    # ... and against the CPU oracle on the same Philox streams
+    orc = oracle.DmcEnsemble(oracle.model_from_cfc(spec.cfc_spec), pos[:480],
+                             1e-3, 512, 480, 0.5, seed=6)
+    assert sa.ref_energy == pytest.approx(orc.st.ref_energy, rel=1e-10)
+    for t in range(5):
+        o = orc.step()
+        assert int(ser_a.num_walkers[t]) == o.num_walkers, t
+        assert ser_a.energy[t] == pytest.approx(o.energy, rel=1e-9), t
+        assert ser_a.ref_energy[t] == pytest.approx(o.ref_energy, rel=1e-9), t
     for h in (a, b, v):
         h.close()
     eng.close()
