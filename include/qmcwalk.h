@@ -124,6 +124,14 @@ int qmc_model_one_body_table_info(const qmc_model_params *model,
 int qmc_model_trig_table_info(const qmc_model_params *model, int32_t *rows,
                               double *max_err);
 
+/* Diagnostic (no GPU needed): the kernels' natural logarithm (row table of
+ * 1/c and log c + five terms of log1p; it takes the place of numpy's log in
+ * log|psi| = sum log f, the Metropolis test log(u) < 2 (log|psi'| - log|psi|),
+ * qmc_base/vmc.py:636, and the Box-Muller normals) restated on the host: rows
+ * and the worst |error| / (1 + |log x|) against long double over 2*10^5
+ * arguments of every size. */
+int qmc_log_table_info(int32_t *rows, double *max_err);
+
 /* ---- engine: model constants on one device --------------------------- */
 int qmc_engine_create(const qmc_model_params *model, int device, void *stream,
                       qmc_engine **out);

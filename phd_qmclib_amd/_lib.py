@@ -71,6 +71,7 @@ SIGNATURES = {
                                                 C.POINTER(C.c_int32), _dp]),
     'qmc_model_trig_table_info': (C.c_int, [C.POINTER(ModelParams),
                                             C.POINTER(C.c_int32), _dp]),
+    'qmc_log_table_info': (C.c_int, [C.POINTER(C.c_int32), _dp]),
     'qmc_engine_create': (C.c_int, [C.POINTER(ModelParams), C.c_int, _vp,
                                     C.POINTER(_vp)]),
     'qmc_engine_create_on_stream': (C.c_int, [C.POINTER(ModelParams), C.c_int,

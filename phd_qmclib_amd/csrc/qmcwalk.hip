@@ -695,6 +695,65 @@ extern "C" int qmc_model_trig_table_info(const qmc_model_params *model,
     return 0;
 }
 
+// Diagnostic, no GPU needed: log_pos (qmc_math.h) restated on the host,
+// operation for operation, over 10^5 arguments between 1e-300 and 1e300 and
+// a dense sweep around 1; worst |got - log x| / (1 + |log x|) against long
+// double.
+static const double g_log_tab_host[2 * QMC_LOG_ROWS] = { QMC_LOG_TAB_VALUES };
+
+static double log_pos_host(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01;
+    const double LN2_LO = 1.90821492927058770002e-10;
+    int fe;
+    frexp(x * 1.41421356237309504880, &fe);
+    const int nk = 1 - fe;
+    const double m = ldexp(x, nk);
+    int r = (int)((m - QMC_LOG_LO) * QMC_LOG_INVW);
+    r = r < 0 ? 0 : (r > QMC_LOG_ROWS - 1 ? QMC_LOG_ROWS - 1 : r);
+    const double inv_c = g_log_tab_host[2 * r], L = g_log_tab_host[2 * r + 1];
+    const double d = fma(m, inv_c, -1.0);
+    double q = fma(d, 0.2, -0.25);
+    q = fma(q, d, 1.0 / 3.0);
+    q = fma(q, d, -0.5);
+    const double lm = fma(d * d, q, d) + L;
+    const double kd = (double)nk;
+    return fma(-kd, LN2_HI, fma(-kd, LN2_LO, lm));
+}
+
+extern "C" int qmc_log_table_info(int32_t *rows, double *max_err)
+{
+    if (rows) *rows = QMC_LOG_ROWS;
+    double worst = 0.0;
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 200000; ++i) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const double u = (double)(state >> 11) * (1.0 / 9007199254740992.0);
+        double x;
+        if (i < 100000) x = pow(10.0, -300.0 + 600.0 * u);          // any size
+        else if (i < 150000) x = 1.0 + (u - 0.5) * 1e-3 * (i % 1000); // near 1
+        else x = u + 1e-17;                                          // (0, 1)
+        const long double ref = logl((long double)x);
+        const double err = (double)(fabsl((long double)log_pos_host(x) - ref) /
+                                    (1.0L + fabsl(ref)));
+        if (err > worst) worst = err;
+    }
+    // row edges
+    for (int r = 0; r <= QMC_LOG_ROWS; ++r) {
+        for (int s = -1; s <= 1; ++s) {
+            double x = QMC_LOG_LO + (double)r / QMC_LOG_INVW;
+            if (s < 0) x = nextafter(x, 0.0);
+            if (s > 0) x = nextafter(x, 2.0);
+            const long double ref = logl((long double)x);
+            const double err = (double)(fabsl((long double)log_pos_host(x) - ref) /
+                                        (1.0L + fabsl(ref)));
+            if (err > worst) worst = err;
+        }
+    }
+    if (max_err) *max_err = worst;
+    return 0;
+}
+
 extern "C" int qmc_engine_create(const qmc_model_params *model, int device,
                                  void *stream, qmc_engine **out)
 {

@@ -89,3 +89,14 @@ def test_one_body_table_matches_closed_forms():
             C.byref(mp), C.byref(m1), C.byref(m2), C.byref(err)) == 0
         assert m1.value > 0 and m2.value > 0
         assert err.value < 5e-15
+
+
+def test_log_row_table_matches_long_double():
+    """qmc_math.h log_pos restated on the host by the library's diagnostic."""
+    import ctypes as C
+    from phd_qmclib_amd import _lib
+    lib = _lib.load()
+    rows, err = C.c_int32(0), C.c_double(0)
+    assert lib.qmc_log_table_info(C.byref(rows), C.byref(err)) == 0
+    assert rows.value == 256
+    assert 0 < err.value < 2.5e-16
