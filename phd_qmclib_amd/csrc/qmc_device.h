@@ -1507,11 +1507,19 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // prodL holds every pair's |Y|, prodS the short ones (cos > 0):
         // long product = prodL / prodS (mantissas; exponents kept apart)
         const double prodS_d = (double)prodS, prodL_d = (double)prodL;
-        double lw = log_pos(prod1 * prodS_d) +
-                    m.beta * log_pos(fabs(fast_div(prodL_d, prodS_d))) +
-                    LN2 * ((double)(expS + exp1) +
-                           m.beta * (double)(expL - expS)) -
-                    xoff_sum;
+        // log(prod1 prodS) + beta log|prodL / prodS| as two logarithms and no
+        // division (from the table the one-body factors arrive as logarithms:
+        // prod1 = 1)
+        double lw;
+        if (!m.is_free && m.ob_table) {
+            const double lS = log_pos(prodS_d);
+            lw = fma(m.beta, log_pos(fabs(prodL_d)) - lS, lS);
+        } else {
+            lw = log_pos(prod1 * prodS_d) +
+                 m.beta * log_pos(fabs(fast_div(prodL_d, prodS_d)));
+        }
+        lw += LN2 * ((double)(expS + exp1) + m.beta * (double)(expL - expS)) -
+              xoff_sum;
         if (!WAVE_COUNT) lw += (double)nshort * m.log_am;
         if (MSUM) {
             wave_sum2_mfma(e_lane, lw, E, logwf);
