@@ -128,8 +128,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0,
 
 __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo)
 {
-    uint64_t b = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
-    return (double)b * (1.0 / 9007199254740992.0);
+    // ((hi >> 5) 2^26 + (lo >> 6)) 2^-53, assembled from two exact 32-bit
+    // conversions (6 instructions; through a 64-bit integer the compiler
+    // needs 12) -- every step is exact, the value is the same
+    const double a = (double)(hi >> 5);     // 27 bits
+    const double b = (double)(lo >> 6);     // 26 bits
+    return fma(a, 0x1p-27, b * 0x1p-53);
 }
 
 __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint32_t slot,
