@@ -213,11 +213,29 @@ __device__ __forceinline__ int lane_particle(const DevModel &m, int gl, int p)
     return gl < ge ? gl + ge * p : m.n;
 }
 
+// Sum over the lanes of a group, in every lane.  Inside a row of 16 lanes four
+// DPP rotations (row_ror 8, 4, 2, 1: two v_mov_dpp + one add each, no LDS);
+// across rows the xor butterfly through ds_bpermute.
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N,
+                                               0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N,
+                                               0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum(double v)
 {
+    static_assert(G >= 16, "lane groups are 16, 32 or 64 lanes");
+    v += row_ror_f64<8>(v);
+    v += row_ror_f64<4>(v);
+    v += row_ror_f64<2>(v);
+    v += row_ror_f64<1>(v);
 #pragma unroll
-    for (int m = 1; m < G; m <<= 1)
+    for (int m = 16; m < G; m <<= 1)
         v += __shfl_xor(v, m, 64);
     return v;
 }
