@@ -28,12 +28,14 @@ def eng64():
     e.close()
 
 
-def test_vmc_chains_do_not_depend_on_ensemble_size(eng64):
-    """Chain c follows the same trajectory in an ensemble of 2^16 chains and
-    in one of 300 (Philox stream = chain index), and a rerun is bit-identical."""
+@pytest.mark.parametrize('log2w', [16, 20])      # 20: BASELINE configs[1]
+def test_vmc_chains_do_not_depend_on_ensemble_size(eng64, log2w):
+    """Chain c follows the same trajectory in an ensemble of 2^16 (2^20: the
+    benchmarked size) chains and in one of 300 (Philox stream = chain index),
+    and a rerun is bit-identical."""
     from phd_qmclib_amd.engine import VmcEnsemble
     rng = np.random.RandomState(1)
-    W = 1 << 16
+    W = 1 << log2w
     pos = 64 * rng.random_sample((W, 64))
     big = VmcEnsemble(eng64, W, 0.125, rng_seed=5)
     big.set_state(pos)
@@ -64,13 +66,15 @@ def test_vmc_chains_do_not_depend_on_ensemble_size(eng64):
         h.close()
 
 
-def test_dmc_step_identities_at_scale(eng64):
-    """2^16 walkers: unit weights after branching (W_t == n_w), E_t equals the
-    sum of the yielded walkers' energies, the cloning table is non-decreasing
-    and only references parents, population capped, rerun bit-identical."""
+@pytest.mark.parametrize('log2w', [16, 18])      # 18: BASELINE configs[2]
+def test_dmc_step_identities_at_scale(eng64, log2w):
+    """2^16 (2^18: the benchmarked size) walkers: unit weights after branching
+    (W_t == n_w), E_t equals the sum of the yielded walkers' energies, the
+    cloning table is non-decreasing and only references parents, population
+    capped, rerun bit-identical."""
     from phd_qmclib_amd.engine import DmcEnsemble
     rng = np.random.RandomState(2)
-    target = 1 << 16
+    target = 1 << log2w
     maxw = target * 512 // 480
     pos = 64 * rng.random_sample((target, 64))
 
