@@ -8,6 +8,14 @@
 
 static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 
+// a wave-uniform 64-bit value as the compiler can see it (scalar registers)
+__device__ __forceinline__ long long qmc_uniform(long long v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)v);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
 // Minimum waves per SIMD asked of the register allocator: the N <= 64 shape
 // needs 66 VGPRs left to itself (7 waves); held to 64 it spills one double and
 // runs 8 waves, +1.5 % on the VMC step (profiles/r02_ab_variants.txt).
@@ -163,6 +171,19 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // flagged ACCEPTED (qmc_base/vmc.py:616-618): a forced zero move.
     const bool forced = a.forced != 0;
 
+    // The chain's scalars are needed only after the pair sum; their loads are
+    // issued here so that the memory latency runs under it.  One chain per
+    // wavefront: the index is wave-uniform and the loads are scalar (SGPR
+    // results, no vector registers held across the pair sum).
+    const long long wl = (G == 64) ? qmc_uniform(wr) : wr;
+    double wf_cur = a.wf[wl];
+    double e_cur = a.ecarry[wl];
+    double se = 0.0, se2 = 0.0;
+    long long na = 0;
+    if (G == 64 && !a.reset_sums) {
+        se = a.sum_e[wl]; se2 = a.sum_e2[wl]; na = a.n_acc[wl];
+    }
+
     QMC_SECTION("load+philox+wrap");
     double zn[P];
     int labn[P];              // original particle index held by each lane
@@ -250,8 +271,6 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
         }
     }
     if (!active) return;
-    double wf_cur = a.wf[w];
-    double e_cur = a.ecarry[w];
     // Metropolis test (qmc_base/vmc.py:636)
     // log(u) <= 0: an uphill move needs no logarithm (wave-uniform when one
     // wavefront owns one chain)
@@ -283,9 +302,9 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
         }
     }
     if (gl == 0) {
-        double se = a.reset_sums ? 0.0 : a.sum_e[w];
-        double se2 = a.reset_sums ? 0.0 : a.sum_e2[w];
-        long long na = a.reset_sums ? 0 : a.n_acc[w];
+        if (G != 64 && !a.reset_sums) {
+            se = a.sum_e[w]; se2 = a.sum_e2[w]; na = a.n_acc[w];
+        }
         a.wf[w] = wf_cur;
         a.ecarry[w] = e_cur;
         a.sum_e[w] = se + e_cur;
@@ -353,7 +372,16 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     const double ref_energy = a.ctl->ref_energy;
     // slots that existed at the previous (even) step have a stored normal
     const long long spare_nw = a.ctl->spare_nw;
-    const long long par = a.ref[sr];
+    // (one walker per wavefront: the slot index is wave-uniform, the parent id
+    // and the two energies the weight needs after the pair sum are scalar loads
+    // issued here, their latency under everything else)
+    const long long su = (G == 64) ? qmc_uniform(sr) : sr;
+    const long long par = a.ref[su];
+    double e_par = 0.0, e_slot = 0.0;
+    if (G == 64) {
+        e_par = a.penergy[par];
+        e_slot = a.eslot[su];
+    }
 
     double z[P];
     int lab[P];
@@ -419,10 +447,10 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         if (i < n) a.cdrift[s * n + i] = F[p];
     }
     if (gl == 0) {
-        double e_par = a.penergy[par];
+        if (G != 64) { e_par = a.penergy[par]; e_slot = a.eslot[s]; }
         // the reference averages with the energy slot s held in
         // the previous iteration (jastrow/dmc.py:810), not the parent's.
-        double e_old = a.fix_stale ? e_par : a.eslot[s];
+        double e_old = a.fix_stale ? e_par : e_slot;
         double mean_energy = (e_next + e_old) / 2;
         a.cenergy[s] = e_next;
         a.cweight[s] = exp(-a.dt * (mean_energy - ref_energy));
