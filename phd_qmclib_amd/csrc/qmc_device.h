@@ -533,21 +533,34 @@ __device__ __forceinline__ void sincos_small(double d, double &s, double &c)
     c = fma(d2, fma(d2, sconst(1.0 / 24.0), -0.5), 1.0);
 }
 
-__device__ __forceinline__ bool trig_tab(const DevModel &m, double z, PTab &ta)
+struct TrigRow {
+    double S1, C1, S2, C2;   // the row
+    double dz;               // position inside it
+};
+
+// the row's loads, issued early (the one-body factor is evaluated under their
+// latency); false -- for the whole wavefront -- if a lane is outside the table
+__device__ __forceinline__ bool trig_tab_load(const DevModel &m, double z,
+                                              TrigRow &t)
 {
     const int r = (int)(z * m.tg_inv_h);          // truncation
     if (__ballot((unsigned)r >= (unsigned)m.tg_rows)) return false;
-    const double dz = fma(-(double)r, m.tg_h, z); // [0, h): r h is exact
+    t.dz = fma(-(double)r, m.tg_h, z);            // [0, h): r h is exact
     const qmc_gptr row = (qmc_gptr)m.trig_table + 4u * (unsigned)r;
-    const double S1 = row[0], C1 = row[1], S2 = row[2], C2 = row[3];
-    double sd, cd;
-    sincos_small(fma(dz, m.tg_a1, m.tg_b1), sd, cd);
-    ta.s = fma(S1, cd, C1 * sd);
-    ta.c = fma(C1, cd, -(S1 * sd));
-    sincos_small(fma(dz, m.tg_a2, m.tg_b2), sd, cd);
-    ta.su = fma(S2, cd, C2 * sd);
-    ta.cu = fma(C2, cd, -(S2 * sd));
+    t.S1 = row[0]; t.C1 = row[1]; t.S2 = row[2]; t.C2 = row[3];
     return true;
+}
+
+__device__ __forceinline__ void trig_tab_finish(const DevModel &m,
+                                                const TrigRow &t, PTab &ta)
+{
+    double sd, cd;
+    sincos_small(fma(t.dz, m.tg_a1, m.tg_b1), sd, cd);
+    ta.s = fma(t.S1, cd, t.C1 * sd);
+    ta.c = fma(t.C1, cd, -(t.S1 * sd));
+    sincos_small(fma(t.dz, m.tg_a2, m.tg_b2), sd, cd);
+    ta.su = fma(t.S2, cd, t.C2 * sd);
+    ta.cu = fma(t.C2, cd, -(t.S2 * sd));
 }
 
 // One-body factor (mrbp_qmc/model.py:404-464) and lattice potential (:533-551).
@@ -1080,6 +1093,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         ok[a] = !PAD || lane_particle<G, P, PAD>(m, gl, a) < n;
         F[a] = 0.0; T[a] = 0; Kown[a] = 0; KT[a] = 0;
         if (ITH) kin1[a] = 0.0;
+        // (the row of the pair-table angles is requested first: 10 registers
+        // wait for it while the one-body factor is evaluated)
+        TrigRow trow;
+        const bool trig_ok = !m.is_ideal && m.trig_table &&
+                             trig_tab_load(m, z[a], trow);
         // the one-body factor first: its table rows (or its transcendental
         // branches) are done with before the pair tables occupy registers
         if (!m.is_free && m.ob_table) {
@@ -1123,7 +1141,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         __builtin_amdgcn_sched_barrier(0);
         if (!m.is_ideal) {
             PTab ta;
-            if (!(m.trig_table && trig_tab(m, z[a], ta))) {
+            if (trig_ok) {
+                trig_tab_finish(m, trow, ta);
+            } else {
                 sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
                 sincos_halfpi(z[a] * m.k2_2pi, ta.su, ta.cu);
             }
