@@ -1003,6 +1003,9 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 #ifndef QMC_LEAD_SHORT
 #define QMC_LEAD_SHORT 1
 #endif
+#ifndef QMC_ROLLED_LOOP
+#define QMC_ROLLED_LOOP 1
+#endif
 #ifndef QMC_TWOCASE
 #define QMC_TWOCASE 1
 #endif
@@ -1369,6 +1372,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 QMC_FOLD(prodL, expL);                                        \
             }                                                                 \
         }
+#if QMC_ROLLED_LOOP
+#define QMC_ROLL_PRAGMA _Pragma("clang loop unroll(disable)")
+#else
+#define QMC_ROLL_PRAGMA
+#endif
 #define QMC_PASS(H)                                                           \
         if ((H) < NPASS) {                                                    \
             if (NPASS > 1) {                                                  \
@@ -1382,6 +1390,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             /* (kept rolled: unrolled, the scheduler hoists the LDS reads of \
                every copy and the kernel loses half its occupancy: -8 %) */  \
             QMC_SECTION("rotation_loop_body");                                \
+            QMC_ROLL_PRAGMA                                                   \
             for (int k = ((H) == 0 ? k_first : 1); k < ge / 2; ++k)           \
                 QMC_KSTEP(H, k, false)                                        \
             QMC_SECTION("rotation_last_step");                                \
