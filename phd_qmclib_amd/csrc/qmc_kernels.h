@@ -27,7 +27,7 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
 #define QMC_LB_WAVES , ((G == 64 && P == 1) ? QMC_LB_P1 : 1)
 // (The VMC step of the exact N <= 128 shape held to 96 registers for a fifth
 // wave was 2.4 % faster with the four-case form; with the two-case form it needs
-// 100 registers unconstrained and the constraint costs 2.5 %: off.)
+// 108 registers unconstrained (4 waves) and the constraint costs 2.5 %: off.)
 #ifndef QMC_LB_VMC_P2
 #define QMC_LB_VMC_P2 1
 #endif
