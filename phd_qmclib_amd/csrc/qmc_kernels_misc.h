@@ -150,6 +150,46 @@ __global__ void __launch_bounds__(BLOCK) branch_scatter_kernel(BranchArgs a)
     branch_scatter_tile(a, tile, tile_off);
 }
 
+struct FinishArgs {
+    DmcCtl *ctl;
+    const double *total;      // global (E_t, W_t) or null -> local values
+    const double *block_esum; // per-tile partials to sum here (E_t, unit
+                              // weights) or null -> ctl->e_t / w_t are set
+    double *ser_e, *ser_w, *ser_ref, *ser_acc;
+    unsigned long long *ser_nw;
+    long long ser_idx;
+    double kappa, dt, target;
+};
+
+// E_ref feedback (qmc_base/dmc.py:759-785) + per-step series; one thread.
+__device__ __forceinline__ void dmc_finish_body(const FinishArgs &a, double e_sum)
+{
+    DmcCtl *c = a.ctl;
+    double e_t, w_t;
+    if (a.total) { e_t = a.total[0]; w_t = a.total[1]; }
+    else if (a.block_esum) { e_t = e_sum; w_t = (double)c->nw; }
+    else { e_t = c->e_t; w_t = c->w_t; }
+    c->total_energy += e_t;
+    c->total_weight += w_t;
+    double accum = c->total_energy / c->total_weight;
+    double ref = accum - a.kappa * log(w_t / a.target) / a.dt;
+    c->ref_energy = ref;
+    c->e_t = e_t;
+    c->w_t = w_t;
+    if (a.ser_e) {
+        a.ser_e[a.ser_idx] = e_t;
+        a.ser_w[a.ser_idx] = w_t;
+        a.ser_nw[a.ser_idx] = (unsigned long long)c->nw;
+        a.ser_ref[a.ser_idx] = ref;
+        a.ser_acc[a.ser_idx] = accum;
+    }
+    // an even step stored spare normals for slots [0, nw); they are consumed
+    // by the next (odd) step and invalid afterwards
+    c->spare_nw = (c->step & 1u) ? 0 : c->nw;
+    c->prev_nw = c->nw;
+    c->step += 1;
+}
+
 // Small populations (at most BR_FUSED_TILES tiles of 1024 parents, i.e. the
 // reference's default 480 / 512 walkers): the whole branching step -- counts,
 // scan, cloning table, E_t and W_t -- in ONE workgroup.  There a time step
@@ -159,9 +199,18 @@ __global__ void __launch_bounds__(BLOCK) branch_scatter_kernel(BranchArgs a)
 // 22 -> 32 us.)
 static constexpr int BR_FUSED_TILES = 2;
 
+// (`fin`: the bookkeeping of the PREVIOUS time step, which otherwise is a launch
+// of its own between that step's drift-diffusion and this branching: inside a
+// block of steps it rides at the head of this kernel -- 3 -> 2 dependent
+// launches per step.)
 __global__ void __launch_bounds__(BLOCK)
-branch_fused_kernel(BranchArgs a, double *partial)
+branch_fused_kernel(BranchArgs a, double *partial, FinishArgs fin, int do_fin)
 {
+    if (do_fin) {
+        if (threadIdx.x == 0) dmc_finish_body(fin, 0.0);
+        __threadfence_block();
+        __syncthreads();
+    }
     const long long prev_nw = a.ctl->prev_nw;
     const int used = (int)((prev_nw + BR_TILE - 1) / BR_TILE);
     for (int tile = 0; tile < used; ++tile) branch_count_tile(a, tile);
@@ -218,48 +267,13 @@ dmc_local_sums_kernel(const double *block_esum, DmcCtl *ctl, double *partial)
     }
 }
 
-struct FinishArgs {
-    DmcCtl *ctl;
-    const double *total;      // global (E_t, W_t) or null -> local values
-    const double *block_esum; // per-tile partials to sum here (E_t, unit
-                              // weights) or null -> ctl->e_t / w_t are set
-    double *ser_e, *ser_w, *ser_ref, *ser_acc;
-    unsigned long long *ser_nw;
-    long long ser_idx;
-    double kappa, dt, target;
-};
-
-// E_ref feedback (qmc_base/dmc.py:759-785) + per-step series.
 __global__ void __launch_bounds__(BLOCK) dmc_finish_kernel(FinishArgs a)
 {
     __shared__ double sh[BLOCK];
-    DmcCtl *c = a.ctl;
     double e_sum = 0.0;
-    if (a.block_esum) e_sum = sum_block_esum(a.block_esum, c, sh);
+    if (a.block_esum) e_sum = sum_block_esum(a.block_esum, a.ctl, sh);
     if (threadIdx.x != 0) return;
-    double e_t, w_t;
-    if (a.total) { e_t = a.total[0]; w_t = a.total[1]; }
-    else if (a.block_esum) { e_t = e_sum; w_t = (double)c->nw; }
-    else { e_t = c->e_t; w_t = c->w_t; }
-    c->total_energy += e_t;
-    c->total_weight += w_t;
-    double accum = c->total_energy / c->total_weight;
-    double ref = accum - a.kappa * log(w_t / a.target) / a.dt;
-    c->ref_energy = ref;
-    c->e_t = e_t;
-    c->w_t = w_t;
-    if (a.ser_e) {
-        a.ser_e[a.ser_idx] = e_t;
-        a.ser_w[a.ser_idx] = w_t;
-        a.ser_nw[a.ser_idx] = (unsigned long long)c->nw;
-        a.ser_ref[a.ser_idx] = ref;
-        a.ser_acc[a.ser_idx] = accum;
-    }
-    // an even step stored spare normals for slots [0, nw); they are consumed
-    // by the next (odd) step and invalid afterwards
-    c->spare_nw = (c->step & 1u) ? 0 : c->nw;
-    c->prev_nw = c->nw;
-    c->step += 1;
+    dmc_finish_body(a, e_sum);
 }
 
 // ---- DMC estimators ------------------------------

@@ -1568,8 +1568,33 @@ extern "C" int qmc_dmc_set_tape(qmc_dmc *d, const double *u, int64_t nu,
     return 0;
 }
 
-// Enqueue the rank-local part of one time step.
-static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev)
+static FinishArgs dmc_finish_args(qmc_dmc *d, const double *total_dev,
+                                  long long ser_idx)
+{
+    FinishArgs f;
+    f.ctl = d->ctl; f.total = total_dev;
+    f.block_esum = (!total_dev && d->sums_pending) ? d->block_esum : nullptr;
+    const bool rec = ser_idx >= 0;
+    f.ser_e = rec ? d->ser_e : nullptr; f.ser_w = d->ser_w;
+    f.ser_ref = d->ser_ref; f.ser_acc = d->ser_acc; f.ser_nw = d->ser_nw;
+    f.ser_idx = ser_idx;
+    f.kappa = d->p.num_walkers_control_factor; f.dt = d->p.time_step;
+    f.target = d->global_target;
+    return f;
+}
+
+// Small populations run the whole branching step in one workgroup
+// (branch_fused_kernel), which can also carry the previous step's bookkeeping.
+static bool dmc_fused_branching(const qmc_dmc *d)
+{
+    return d->nblocks <= BR_FUSED_TILES;
+}
+
+// Enqueue the rank-local part of one time step.  `prev_fin`: the bookkeeping of
+// the step before, to ride at the head of the fused branching kernel (only
+// where dmc_fused_branching(d)).
+static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev,
+                             const FinishArgs *prev_fin = nullptr)
 {
     qmc_engine *e = d->eng;
     const int par = d->cur, chi = 1 - d->cur;
@@ -1587,11 +1612,15 @@ static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev)
     b.block_esum = d->block_esum; b.ref = d->ref; b.ctl = d->ctl;
     b.u_tape = ut; b.maxw = d->maxw; b.seed = d->p.rng_seed;
     b.slot0 = d->p.slot0;
-    if (d->nblocks <= BR_FUSED_TILES) {
+    if (dmc_fused_branching(d)) {
         d->sums_pending = false;
+        FinishArgs none{};
         hipLaunchKernelGGL(branch_fused_kernel, dim3(1), dim3(BLOCK), 0,
-                           e->stream, b, partial_dev);
+                           e->stream, b, partial_dev,
+                           prev_fin ? *prev_fin : none, prev_fin ? 1 : 0);
     } else {
+        if (prev_fin) return fail("qmc_dmc: internal: deferred bookkeeping "
+                                  "needs the fused branching kernel");
         hipLaunchKernelGGL(branch_count_kernel, dim3(d->nblocks), dim3(BLOCK),
                            0, e->stream, b);
         hipLaunchKernelGGL(branch_scatter_kernel, dim3(d->nblocks),
@@ -1623,15 +1652,7 @@ static int dmc_enqueue_finish(qmc_dmc *d, const double *total_dev,
                               long long ser_idx)
 {
     qmc_engine *e = d->eng;
-    FinishArgs f;
-    f.ctl = d->ctl; f.total = total_dev;
-    f.block_esum = (!total_dev && d->sums_pending) ? d->block_esum : nullptr;
-    const bool rec = ser_idx >= 0;
-    f.ser_e = rec ? d->ser_e : nullptr; f.ser_w = d->ser_w;
-    f.ser_ref = d->ser_ref; f.ser_acc = d->ser_acc; f.ser_nw = d->ser_nw;
-    f.ser_idx = ser_idx;
-    f.kappa = d->p.num_walkers_control_factor; f.dt = d->p.time_step;
-    f.target = d->global_target;
+    const FinishArgs f = dmc_finish_args(d, total_dev, ser_idx);
     hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(BLOCK), 0, e->stream,
                        f);
     HIP_TRY(hipGetLastError());
@@ -1677,12 +1698,40 @@ extern "C" int qmc_dmc_run_block(qmc_dmc *d, int64_t nsteps, double *energy,
     HIP_TRY(hipSetDevice(d->eng->device));
     if (dmc_reserve_series(d, nsteps)) return 1;
     d->ser_len = 0;
-    for (long long t = 0; t < nsteps; ++t) {
-        int rc = dmc_enqueue_local(d, nullptr);
-        if (rc) return rc;
-        rc = dmc_enqueue_finish(d, nullptr, t);
-        if (rc) return rc;
-        d->ser_len = t + 1;
+    if (dmc_fused_branching(d)) {
+        // small population: a step costs the latency of its dependent
+        // launches.  The bookkeeping of step t rides at the head of step
+        // t + 1's branching kernel (same order on the stream as its own
+        // launch would have); only the last step of the block launches it.
+        FinishArgs pend{};
+        bool have = false;
+        for (long long t = 0; t < nsteps; ++t) {
+            int rc = dmc_enqueue_local(d, nullptr, have ? &pend : nullptr);
+            if (rc) {
+                // (nothing was launched for this step: the step before still
+                // needs its bookkeeping)
+                if (have)
+                    hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(BLOCK),
+                                       0, d->eng->stream, pend);
+                return rc;
+            }
+            pend = dmc_finish_args(d, nullptr, t);
+            have = true;
+            d->cur = 1 - d->cur;          // children become the parents
+            d->stepped = true;
+            d->ser_len = t + 1;
+        }
+        hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(BLOCK), 0,
+                           d->eng->stream, pend);
+        HIP_TRY(hipGetLastError());
+    } else {
+        for (long long t = 0; t < nsteps; ++t) {
+            int rc = dmc_enqueue_local(d, nullptr);
+            if (rc) return rc;
+            rc = dmc_enqueue_finish(d, nullptr, t);
+            if (rc) return rc;
+            d->ser_len = t + 1;
+        }
     }
     if (energy || weight || num_walkers || ref_energy || accum_energy)
         return qmc_dmc_read_series(d, nsteps, energy, weight, num_walkers,
