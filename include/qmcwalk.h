@@ -164,6 +164,16 @@ int qmc_engine_profile_begin(qmc_engine *eng, int64_t max_launches);
 int qmc_engine_profile_end(qmc_engine *eng, int64_t *launches,
                            double *total_ms, double *min_ms, double *max_ms);
 
+/* Diagnostic (no reference counterpart): a library built
+ * with -DQMC_TIMING stamps the shader clock at the section marks of the walker
+ * kernels; this returns, per section, the cycles of wavefront lifetime spent
+ * in it and the number of visits since the last reset (nsec must be 32;
+ * entries 16..31 are the sections inside the energy pass of the VMC step).
+ * The shipped library carries no stamps and returns an error. */
+int qmc_engine_section_profile(qmc_engine *eng, uint64_t *cycles,
+                               uint64_t *visits, int32_t nsec, int32_t reset);
+const char *qmc_section_name(int32_t section);
+
 /* Stands in for model.core_funcs.{wf_abs_log, energy, drift,
  * ith_energy_and_drift} (qmc_base/jastrow/model.py:298-366, 476-564, 756-773,
  * 793-854) over a batch of configurations.  Host buffers; any output may be

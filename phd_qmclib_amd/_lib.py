@@ -81,6 +81,10 @@ SIGNATURES = {
     'qmc_engine_stream': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
     'qmc_engine_profile_begin': (C.c_int, [_vp, C.c_int64]),
     'qmc_engine_profile_end': (C.c_int, [_vp, _i64p, _dp, _dp, _dp]),
+    'qmc_engine_section_profile': (C.c_int, [_vp, C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint64), C.c_int32,
+                                             C.c_int32]),
+    'qmc_section_name': (C.c_char_p, [C.c_int32]),
     'qmc_engine_sync': (C.c_int, [_vp]),
     'qmc_engine_timer_start': (C.c_int, [_vp]),
     'qmc_engine_timer_stop': (C.c_int, [_vp, C.POINTER(C.c_float)]),

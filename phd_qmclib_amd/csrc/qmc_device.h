@@ -35,13 +35,44 @@
 
 #define QMC_PI 3.141592653589793238462643383279502884
 
-// Section markers for the static instruction census (tools/isa_one.sh builds
-// with -DQMC_SECTIONS; the production build emits nothing).
-#ifdef QMC_SECTIONS
+// Section markers.  Production build: nothing.  -DQMC_SECTIONS (tools/isa_one.sh):
+// a comment in the ISA for the static instruction census.  -DQMC_TIMING (the
+// diagnostic library of tools/section_times.py, never the shipped one): every
+// mark reads the shader clock (s_memtime) and lane 0 adds the time since the
+// wavefront's previous mark to the section that ends there -- the share of a
+// wavefront's lifetime each section takes, measured while the kernel runs
+// (qmc_engine_section_profile).
+#define QMC_NSEC 32
+#define QMC_SEC_COPIES 1024
+#if defined(QMC_TIMING)
+#define QMC_SECTION(name) qmc_stamp(m, qmc_sec_id(name))
+#define QMC_SECTION_PHASE(off) qmc_stamp_phase(off)
+#elif defined(QMC_SECTIONS)
 #define QMC_SECTION(name) asm volatile("; SECTION " name)
+#define QMC_SECTION_PHASE(off) do { } while (0)
 #else
 #define QMC_SECTION(name) do { } while (0)
+#define QMC_SECTION_PHASE(off) do { } while (0)
 #endif
+
+// ids of the sections (a second pass of eval_walker -- the energy pass of the
+// VMC step -- is booked QMC_NSEC / 2 higher, qmc_stamp_phase)
+constexpr const char *QMC_SEC_NAMES[QMC_NSEC / 2] = {
+    "top", "load+philox+wrap", "resort", "tables+onebody", "pairs_in_lane",
+    "leading_neighbour_steps", "leading_short_steps", "rotation",
+    "rotation_loop_body", "rotation_last_step", "energy+logwf",
+    "metropolis+store", "energy_pass", "store", "weight+store", "end" };
+
+constexpr bool qmc_streq(const char *a, const char *b)
+{
+    return *a == *b && (*a == 0 || qmc_streq(a + 1, b + 1));
+}
+constexpr int qmc_sec_id(const char *name)
+{
+    for (int i = 0; i < QMC_NSEC / 2; ++i)
+        if (qmc_streq(name, QMC_SEC_NAMES[i])) return i;
+    return QMC_NSEC / 2 - 1;
+}
 
 struct DevModel {
     int n;                 // boson_number
@@ -56,6 +87,7 @@ struct DevModel {
     double m_k2cphi;       // -k2 cos(k2 r_off)
     double k2sphi;         //  k2 sin(k2 r_off)
     double cphi, sphi;     // cos/sin(k2 r_off)
+    double am_cphi, am_sphi;   // |a_m| times them (qmc_sorted64.h)
     double cth, sth;       // cos(k2 L), |sin(k2 L)|
     int sth_sign;          // sign bit of sin(k2 L) (0 or 0x80000000)
     double sth_signed;     // sin(k2 L)
@@ -97,7 +129,47 @@ struct DevModel {
     double tg_inv_h, tg_h;
     double tg_a1, tg_b1;   // pi/L, -(pi/L) h/2:  angle offset = a dz + b
     double tg_a2, tg_b2;   // k2,   -k2 h/2
+    // QMC_TIMING builds: QMC_SEC_COPIES x ([QMC_NSEC] cycles + [QMC_NSEC]
+    // visits) (else null); a workgroup adds into copy blockIdx.x mod
+    // QMC_SEC_COPIES (every wavefront adding into ONE set of counters
+    // serialises on the atomics: the kernel ran 30x slower)
+    unsigned long long *sec_prof;
 };
+
+#if defined(QMC_TIMING)
+struct QmcStampState {
+    unsigned long long last[4];
+    int cur[4], phase[4];
+};
+__device__ __forceinline__ QmcStampState &qmc_stamp_state()
+{
+    __shared__ QmcStampState st;
+    return st;
+}
+__device__ __forceinline__ void qmc_stamp_phase(int off)
+{
+    if ((threadIdx.x & 63) == 0) qmc_stamp_state().phase[threadIdx.x >> 6] = off;
+}
+__device__ __forceinline__ void qmc_stamp(const DevModel &m, int id)
+{
+    const unsigned long long t = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0 && m.sec_prof) {
+        QmcStampState &st = qmc_stamp_state();
+        const int w = threadIdx.x >> 6;
+        if (id != 0) {
+            // (masked: a kernel without a "top" mark has no valid state)
+            const int c = (st.cur[w] & (QMC_NSEC - 1)) +
+                          2 * QMC_NSEC * (blockIdx.x & (QMC_SEC_COPIES - 1));
+            atomicAdd(&m.sec_prof[c], t - st.last[w]);
+            atomicAdd(&m.sec_prof[QMC_NSEC + c], 1ull);
+        } else {
+            st.phase[w] = 0;
+        }
+        st.cur[w] = id + st.phase[w];
+        st.last[w] = t;
+    }
+}
+#endif
 
 // One-body table row (128 bytes, one cache line per particle): degree OB_DEG
 // polynomials in t in [0, 1) across one interval of the unit cell,
@@ -620,7 +692,7 @@ __device__ __forceinline__ void one_body(const DevModel &m, double z,
 // pair tables occupy registers.
 // `logf1` is log of the factor itself (the direct path returns the factor and
 // a split-off exponent).
-template <bool WF>
+template <bool WF, bool LDZ = true>
 __device__ __forceinline__ void one_body_tab(const DevModel &m, double z,
                                              double &ldz, double &logf1,
                                              bool &barrier)
@@ -640,10 +712,12 @@ __device__ __forceinline__ void one_body_tab(const DevModel &m, double z,
     const unsigned off = (unsigned)(int)u * OB_ROW;
     const double t = __builtin_amdgcn_fract(u);
     const qmc_gptr r = (qmc_gptr)m.ob_table + off;
-    double p = r[OB_DEG];
+    if (LDZ) {
+        double p = r[OB_DEG];
 #pragma unroll
-    for (int k = OB_DEG - 1; k >= 0; --k) p = fma(p, t, r[k]);
-    ldz = p;
+        for (int k = OB_DEG - 1; k >= 0; --k) p = fma(p, t, r[k]);
+        ldz = p;
+    }
     if (WF) {
         double q = r[8 + OB_DEG];
 #pragma unroll
@@ -706,7 +780,7 @@ __device__ __forceinline__ PairConstsT<R> load_pair_consts(const DevModel &m)
 
 // Short-range X, Y of a pair from the k2-tables of both particles, exact for
 // any order of the two and either side of the periodic wrap.
-template <typename R>
+template <typename R, bool EN = true>
 __device__ __forceinline__ void short_generic(const PairConstsT<R> &m,
                                               const PTabT<R> &a,
                                               const PTabT<R> &b, R S,
@@ -747,8 +821,10 @@ __device__ __forceinline__ void short_generic(const PairConstsT<R> &m,
     }
     // now (Su, Cu) = sin/cos(k2 d), |k2 d| < pi/2, sgn(Su) = sgn(d):
     //   -k2 tan(k2 r - phi) sgn(d) = X / Y with
-    R t2 = q_copysign(m.v_k2sphi, Su);
-    X = q_fma(m.m_k2cphi, Su, Cu * t2);
+    if (EN) {
+        R t2 = q_copysign(m.v_k2sphi, Su);
+        X = q_fma(m.m_k2cphi, Su, Cu * t2);
+    }
     Y = q_fma(q_abs(Su), m.sphi, Cu * m.cphi);
 }
 
@@ -762,7 +838,9 @@ __device__ __forceinline__ void short_generic(const PairConstsT<R> &m,
 //             z = 0; classified like real particles they are "short" whenever
 //             their partner is near the box boundary and pull whole wavefronts
 //             through the short-range branches (N = 100: 15 % of the step).
-template <bool ZCLASS, typename R>
+//   EN      : the quotient is wanted (energy / drift); without it only the
+//             factor Yout and the class (the log|psi|-only pass of the VMC step)
+template <bool ZCLASS, typename R, bool EN = true>
 __device__ __forceinline__ void pair_core(const PairConstsT<R> &m,
                                           const PTabT<R> &a, R aks, R akc,
                                           R za, const PTabT<R> &b, R zb,
@@ -771,24 +849,27 @@ __device__ __forceinline__ void pair_core(const PairConstsT<R> &m,
                                           unsigned long long &shortmask)
 {
     R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
-    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R X = 0;
+    if (EN) X = akc * b.c + aks * b.s;   // a_long * cos(...)
     R Y = S;
-    bool wrapped;
+    bool wrapped = false;
     if (ZCLASS) {
         R aD = q_abs(za - zb);
         wrapped = aD > m.half_L;
         isshort = live & ((aD < m.rm) | (aD > m.L_minus_rm));
     } else {
-        wrapped = X < (R)0;               // |z_a - z_b| > L/2
+        if (EN) wrapped = X < (R)0;       // |z_a - z_b| > L/2
         isshort = live & (q_abs(S) < m.sin_rm);   // min-image r < rm
     }
     // taken here, in the block of the compare, the ballot is the compare's own
     // SGPR mask (later it costs a v_cndmask + v_cmp round trip)
     shortmask = __ballot(isshort);
     if (isshort) {
-        short_generic<R>(m, a, b, S, wrapped, X, Y);
+        // (without the quotient the cosine is formed for the short pairs only)
+        if (!EN && !ZCLASS) wrapped = (a.c * b.c + a.s * b.s) < (R)0;
+        short_generic<R, EN>(m, a, b, S, wrapped, X, Y);
     }
-    q = pair_div(X, Y);
+    if (EN) q = pair_div(X, Y);
     Yout = Y;
 }
 
@@ -819,7 +900,7 @@ __device__ __forceinline__ void make_short_tab(const DevModel &m, double su,
     }
 }
 
-template <bool ZCLASS, typename R>
+template <bool ZCLASS, typename R, bool EN = true>
 __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
                                            const PTabT<R> &a,
                                            const ShortTabT<R> &sa, R aks,
@@ -829,9 +910,10 @@ __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
                                            unsigned long long &shortmask)
 {
     R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
-    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R X = 0;
+    if (EN) X = akc * b.c + aks * b.s;   // a_long * cos(...)
     R Y = S;
-    bool wrapped, neg;
+    bool wrapped = false, neg;
     if (ZCLASS) {
         const R D = za - zb;
         const R aD = q_abs(D);
@@ -839,19 +921,20 @@ __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
         neg = D < (R)0;
         isshort = live & ((aD < m.rm) | (aD > m.L_minus_rm));
     } else {
-        wrapped = X < (R)0;               // |z_a - z_b| > L/2
+        if (EN) wrapped = X < (R)0;       // |z_a - z_b| > L/2
         neg = S < (R)0;                   // sgn(D) = sgn(sin(pi D / L))
         isshort = live & (q_abs(S) < m.sin_rm);   // min-image r < rm
     }
     shortmask = __ballot(isshort);
     if (isshort) {
-        R xs, ys;
+        R xs = 0, ys;
+        if (!EN && !ZCLASS) wrapped = (a.c * b.c + a.s * b.s) < (R)0;
         // real (exec-masked) branches: as selects the four cases would cost
         // eight v_cndmask per double pair
 #define QMC_CASE4(v)                                                          \
         {                                                                     \
             asm volatile("");                                                 \
-            xs = sa.s[v] * b.cu - sa.c[v] * b.su;                             \
+            if (EN) xs = sa.s[v] * b.cu - sa.c[v] * b.su;                     \
             ys = sa.c[v] * b.cu + sa.s[v] * b.su;                             \
         }
         if (!wrapped) {
@@ -860,10 +943,10 @@ __device__ __forceinline__ void pair_core4(const PairConstsT<R> &m,
             if (!neg) QMC_CASE4(2) else QMC_CASE4(3)
         }
 #undef QMC_CASE4
-        X = m.m_k2 * xs;
+        if (EN) X = m.m_k2 * xs;
         Y = ys;
     }
-    q = pair_div(X, Y);
+    if (EN) q = pair_div(X, Y);
     Yout = Y;
 }
 
@@ -891,7 +974,7 @@ __device__ __forceinline__ void make_short_tab2(const DevModel &m, double su,
     st.c3 = (R)fma(cu, m.var_cos[3], -(su * m.var_sin[3]));
 }
 
-template <typename R>
+template <typename R, bool EN = true>
 __device__ __forceinline__ void pair_core2(const PairConstsT<R> &m,
                                            const PTabT<R> &a,
                                            const ShortTab2T<R> &sa, R aks,
@@ -900,9 +983,11 @@ __device__ __forceinline__ void pair_core2(const PairConstsT<R> &m,
                                            unsigned long long &shortmask)
 {
     R S = a.s * b.c - a.c * b.s;     // sin(pi (z_a - z_b) / L)
-    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R X = 0;
+    if (EN) X = akc * b.c + aks * b.s;   // a_long * cos(...)
     R Y = S;
-    const bool wrapped = X < (R)0;   // |z_a - z_b| > L/2
+    bool wrapped = false;
+    if (EN) wrapped = X < (R)0;      // |z_a - z_b| > L/2
     const bool neg = S < (R)0;       // sgn(D) = sgn(sin(pi D / L))
     // min-image r < rm.  (`live` = both particles exist: the idle slots of a
     // padded shape hold z = 0 and would otherwise pull whole wavefronts into
@@ -910,18 +995,21 @@ __device__ __forceinline__ void pair_core2(const PairConstsT<R> &m,
     isshort = live & (q_abs(S) < m.sin_rm);
     shortmask = __ballot(isshort);
     if (isshort) {
+        if (!EN) wrapped = (a.c * b.c + a.s * b.s) < (R)0;
         if (wrapped == neg) {
             asm volatile("");
             const R os = neg ? sa.s3 : sa.s0, oc = neg ? sa.c3 : sa.c0;
-            const R xs = os * b.cu - oc * b.su;
             Y = oc * b.cu + os * b.su;
-            X = m.m_k2 * xs;
+            if (EN) {
+                const R xs = os * b.cu - oc * b.su;
+                X = m.m_k2 * xs;
+            }
         } else {
             asm volatile("");
-            short_generic<R>(m, a, b, S, wrapped, X, Y);
+            short_generic<R, EN>(m, a, b, S, wrapped, X, Y);
         }
     }
-    q = pair_div(X, Y);
+    if (EN) q = pair_div(X, Y);
     Yout = Y;
 }
 
@@ -943,7 +1031,7 @@ struct OwnShort1T {
     R ks0, kc0;    // -k2 times the same
 };
 
-template <typename R>
+template <typename R, bool EN = true>
 __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
                                            R ac, const OwnShort1T<R> &o,
                                            R aks, R akc, const PTabT<R> &b,
@@ -953,15 +1041,19 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
                                            unsigned long long &shortmask)
 {
     R S = as * b.c - ac * b.s;       // sin(pi (z_a - z_b') / L)
-    R X = akc * b.c + aks * b.s;     // a_long * cos(...)
+    R X = 0;
+    if (EN) X = akc * b.c + aks * b.s;   // a_long * cos(...)
     R Y = S;
     isshort = live & (q_abs(S) < m.sin_rm);   // min-image r < rm
     shortmask = __ballot(isshort);
     if (isshort) {
+        // (without the quotient only the sign of the cosine is needed, and
+        // only here)
+        if (!EN) X = ac * b.c + as * b.s;
         if ((S > (R)0) & (X > (R)0)) {
             // 0 < D' < L/2: theta = k2 D' - phi, X = -k2 sin, Y = cos
             asm volatile("");
-            X = o.ks0 * b.cu - o.kc0 * b.su;
+            if (EN) X = o.ks0 * b.cu - o.kc0 * b.su;
             Y = o.c0 * b.cu + o.s0 * b.su;
         } else {
             asm volatile("");
@@ -982,13 +1074,168 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
                 const R nc = Cu * m.cth + Su * t;
                 Su = ns; Cu = nc;
             }
-            const R t2 = q_copysign(m.k2sphi, Su);
-            X = q_fma(m.m_k2cphi, Su, Cu * t2);
+            if (EN) {
+                const R t2 = q_copysign(m.k2sphi, Su);
+                X = q_fma(m.m_k2cphi, Su, Cu * t2);
+            }
             Y = q_fma(q_abs(Su), m.sphi, Cu * m.cphi);
         }
     }
-    q = pair_div(X, Y);
+    if (EN) q = pair_div(X, Y);
     Yout = Y;
+}
+
+// log|psi|-only pair loop of the one-walker-per-wavefront, one-particle-per-lane
+// shape with the shifted table copy (pair_core1's world): the first pass of the
+// two-pass VMC step.  Same pair arithmetic and the same phases as the rotation
+// of eval_walker (neighbour steps, leading all-short steps, general steps), but
+// written for latency rather than instruction count: a step here is 4-8 vector
+// instructions, so a wavefront that waits for its LDS read in every step and
+// branches four times per step leaves the vector ALU idle even at eight
+// wavefronts per SIMD (measured with the section stamps: this pass took longer
+// than the energy pass, which executes three times the instructions).  The
+// partner's tables are therefore requested one step (general phase) or one
+// two-step chunk (leading phase) ahead, and the leading phase decides two steps
+// with one scalar test.
+//   prodS/expS : product of the short-range factors cos(k2 r - phi) (mantissa,
+//                binary exponent);  prodL/expL: product of |Y| over ALL pairs
+//   ns_wave    : number of short pairs of the walker
+template <typename R>
+__device__ __forceinline__ void logpsi_pairs64(const PairConstsT<R> &pc, R as,
+                                               R ac, const OwnShort1T<R> &o,
+                                               int gl, const R *lS, const R *lC,
+                                               const R *lSU, const R *lCU,
+                                               R &prodS, int &expS, R &prodL,
+                                               int &expL, int &ns_wave)
+{
+    constexpr int G = 64;
+    // partner of rotation step k: entry (G + gl) - k of the doubled tables
+    const R *pS = lS + G + gl, *pC = lC + G + gl;
+    const R *pSU = lSU + G + gl, *pCU = lCU + G + gl;
+    int k = 1;
+    R P1 = 1;                  // factors of the leading steps (all short)
+    int ns = 0;
+    if (pc.sp_ok) {
+        const R osu = pSU[0], ocu = pCU[0];
+        const R b1su = pSU[-1], b1cu = pCU[-1], b2su = pSU[-2], b2cu = pCU[-2];
+        // first chunk of the one-case steps, requested now
+        R n0su = pSU[-3], n0cu = pCU[-3], n1su = pSU[-4], n1cu = pCU[-4];
+        // k = 1, 2: the form that is exact for either order of the neighbours
+        const R Su1 = osu * b1cu - ocu * b1su, Cu1 = ocu * b1cu + osu * b1su;
+        const R Su2 = osu * b2cu - ocu * b2su, Cu2 = ocu * b2cu + osu * b2su;
+        // |k2 D'| < pi: |D'| < rm iff cos(k2 D') > cos(k2 rm)
+        const bool ok1 = __builtin_amdgcn_ballot_w64(Cu1 > pc.sp_cos) == ~0ull;
+        const bool ok2 = __builtin_amdgcn_ballot_w64(Cu2 > pc.sp_cos) == ~0ull;
+        const R Y1 = q_fma(q_abs(Su1), pc.sphi, Cu1 * pc.cphi);
+        const R Y2 = q_fma(q_abs(Su2), pc.sphi, Cu2 * pc.cphi);
+        bool lead = false;
+        if (ok1 && ok2) { P1 = Y1 * Y2; ns = 2 * G; k = 3; lead = true; }
+        else if (ok1) { P1 = Y1; ns = G; k = 2; }
+        // k = 3 ..: the single case of the shifted tables, two steps per test
+        while (lead && k + 1 < G / 2) {
+            const R b0su = n0su, b0cu = n0cu, b1su_ = n1su, b1cu_ = n1cu;
+            // (k + 3 <= G/2 + 1: inside the doubled tables for every lane)
+            n0su = pSU[-(k + 2)]; n0cu = pCU[-(k + 2)];
+            n1su = pSU[-(k + 3)]; n1cu = pCU[-(k + 3)];
+            const R X0 = o.ks0 * b0cu - o.kc0 * b0su;
+            const R Y0 = o.c0 * b0cu + o.s0 * b0su;
+            const R X1 = o.ks0 * b1cu_ - o.kc0 * b1su_;
+            const R Y1_ = o.c0 * b1cu_ + o.s0 * b1su_;
+            const unsigned long long f0 =
+                __builtin_amdgcn_ballot_w64(X0 > pc.sp_xlo) &
+                __builtin_amdgcn_ballot_w64(X0 < pc.sp_xhi) &
+                __builtin_amdgcn_ballot_w64(Y0 > (R)0);
+            const unsigned long long f1 =
+                __builtin_amdgcn_ballot_w64(X1 > pc.sp_xlo) &
+                __builtin_amdgcn_ballot_w64(X1 < pc.sp_xhi) &
+                __builtin_amdgcn_ballot_w64(Y1_ > (R)0);
+            if ((f0 & f1) == ~0ull) {
+                P1 *= Y0 * Y1_;
+                ns += 2 * G;
+                k += 2;
+                // (factors >= cos(phi): eight steps stay inside the range of
+                // a float as well)
+                if (sizeof(R) == 4 && (k & 7) == 3) {
+                    int e = 0;
+                    q_fold(P1, e);
+                    expS += e; expL += e;
+                }
+            } else {
+                if (f0 == ~0ull) { P1 *= Y0; ns += G; k += 1; }
+                lead = false;
+            }
+        }
+    }
+    // ---- general steps k .. G/2: classified pair by pair ----
+    R PL = 1, PS = 1;
+    int eL = 0, eS = 0;
+    const R own_su = pSU[0], own_cu = pCU[0];
+    R bs = pS[-k], bc = pC[-k];
+    // one step against the partner tables (cs, cc) [+ (su, cu) on demand];
+    // `mine`: this lane tallies the pair
+#define QMC_WF_STEP(mine)                                                     \
+    {                                                                         \
+        const R S = as * cc - ac * cs;        /* sin(pi (z_a - z_b') / L) */   \
+        const bool sh = (mine) & (q_abs(S) < pc.sin_rm); /* min-image r < rm */\
+        ns += __popcll(__builtin_amdgcn_ballot_w64(sh));                      \
+        R Y = S;                                                              \
+        if (sh) {                                                             \
+            const R bsu = pSU[-k], bcu = pCU[-k];                             \
+            const R Xc = ac * cc + as * cs;   /* cos(...): its sign only */    \
+            if ((S > (R)0) & (Xc > (R)0)) {                                   \
+                /* 0 < D' < L/2: Y = cos(k2 D' - phi) */                      \
+                asm volatile("");                                             \
+                Y = o.c0 * bcu + o.s0 * bsu;                                  \
+            } else {                                                          \
+                asm volatile("");                                             \
+                /* any order of the lanes (pair_core1's generic branch) */    \
+                R su_ = bsu, cu_ = bcu, Sg = S, Xg = Xc;                      \
+                if (gl < k) {                                                 \
+                    const R s2 = su_ * pc.cth + cu_ * pc.sth_signed;          \
+                    const R c2 = cu_ * pc.cth - su_ * pc.sth_signed;          \
+                    su_ = s2; cu_ = c2; Sg = -S; Xg = -Xc;                    \
+                }                                                             \
+                R Su = own_su * cu_ - own_cu * su_; /* sin(k2 (z_a - z_b)) */  \
+                R Cu = own_cu * cu_ + own_su * su_;                           \
+                if (Xg < (R)0) {                                              \
+                    const R t = (Sg < (R)0) ? -pc.sth_signed : pc.sth_signed; \
+                    const R ns_ = Su * pc.cth - Cu * t;                       \
+                    const R nc_ = Cu * pc.cth + Su * t;                       \
+                    Su = ns_; Cu = nc_;                                       \
+                }                                                             \
+                Y = q_fma(q_abs(Su), pc.sphi, Cu * pc.cphi);                  \
+            }                                                                 \
+            PS *= Y;                                                          \
+        }                                                                     \
+        if (mine) PL *= Y;                                                    \
+    }
+    for (; k < G / 2; ++k) {
+        const R cs = bs, cc = bc;
+        bs = pS[-(k + 1)]; bc = pC[-(k + 1)];    // the next step's, already
+        QMC_WF_STEP(true)
+        if ((k & (sizeof(R) == 4 ? 7 : 15)) == 0) {
+            asm volatile("");
+            q_fold(PS, eS);
+            q_fold(PL, eL);
+        }
+    }
+    {
+        // the final half step visits every pair from both sides: the lower
+        // half of the lanes tallies
+        const R cs = bs, cc = bc;
+        const bool lower = gl < G / 2;
+        QMC_WF_STEP(lower)
+    }
+#undef QMC_WF_STEP
+    // the leading steps belong to both products
+    int e1 = 0;
+    q_fold(P1, e1);
+    PS *= P1; PL *= P1;
+    q_fold(PS, eS);
+    q_fold(PL, eL);
+    prodS = PS; expS += eS + e1;
+    prodL = PL; expL += eL + e1;
+    ns_wave += ns;
 }
 
 // LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of
@@ -1009,6 +1256,9 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 #ifndef QMC_TWOCASE
 #define QMC_TWOCASE 1
 #endif
+#ifndef QMC_WF_LOOP
+#define QMC_WF_LOOP 1
+#endif
 
 // Tile-sweep knobs of the N = 512 shape (BASELINE.json configs[4]: "LDS
 // tile-size sweep"; tools/tile_sweep.sh builds the variants): own particles per
@@ -1021,21 +1271,33 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
 #define QMC_DUP8 1
 #endif
 
+#ifndef QMC_SORTED64
+#define QMC_SORTED64 1
+#endif
 template <int G, int P, bool ZCLASS>
 struct GroupLds {
     static constexpr int DUP = (P >= 8) ? QMC_DUP8 : ((P >= 2) ? 1 : 2);
     static constexpr int ROW = DUP * G * P;
-    static constexpr int DOUBLES = (ZCLASS ? 5 : 4) * ROW;
+    // (the one-walker-per-wavefront, one-particle-per-lane shape keeps the
+    // positions as a fifth row too: qmc_sorted64.h; 5 KB per wavefront = 32
+    // wavefronts in a CU's 160 KB)
+    static constexpr bool HAS_Z = ZCLASS || (QMC_SORTED64 && G == 64 && P == 1);
+    static constexpr int DOUBLES = (HAS_Z ? 5 : 4) * ROW;
 };
 
 // Evaluate one walker held in registers.
 //   z[P]      : positions owned by this lane (particle index gl + G*a)
 //   F[P]      : out, drift of the own particles
 //   eith[P]   : out if ITH, local energy per particle
-//   E         : out, local energy of the walker (same value in every lane)
+//   E         : out if EN, local energy of the walker (same value in every lane)
 //   logwf     : out if WF, log|psi| (same value in every lane)
+// EN = false is the log|psi|-only pass of the VMC step (no quotients, no
+// drift, no energy: the Metropolis test needs none of them, and the reference
+// evaluates the energy of accepted moves only, qmc_base/jastrow/vmc.py:253-262);
+// REUSE = the pair tables of this configuration are already in LDS (the energy
+// pass after an accepted move).
 template <int G, int P, bool PAD, bool WF, bool ITH, bool ZCLASS,
-          typename R = double>
+          typename R = double, bool EN = true, bool REUSE = false>
 __device__ __forceinline__ void eval_walker(const DevModel &m,
                                             const double (&z)[P], int gl,
                                             double *lds, double (&F)[P],
@@ -1099,15 +1361,17 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         // (the row of the pair-table angles is requested first: 10 registers
         // wait for it while the one-body factor is evaluated)
         TrigRow trow;
-        const bool trig_ok = !m.is_ideal && m.trig_table &&
+        const bool trig_ok = !REUSE && !m.is_ideal && m.trig_table &&
                              trig_tab_load(m, z[a], trow);
         // the one-body factor first: its table rows (or its transcendental
         // branches) are done with before the pair tables occupy registers
         if (!m.is_free && m.ob_table) {
-            double ldz, lf = 0.0;
+            double ldz = 0.0, lf = 0.0;
             bool barrier;
-            one_body_tab<WF>(m, z[a], ldz, lf, barrier);
-            if (WAVE_COUNT && !ITH && m.uniform_barrier) {
+            one_body_tab<WF, EN>(m, z[a], ldz, lf, barrier);
+            if (!EN) {
+                if (WF && ok[a]) xoff_sum -= lf;
+            } else if (WAVE_COUNT && !ITH && m.uniform_barrier) {
                 // one walker per wavefront, every barrier alike: the region
                 // constants are counted on the scalar unit and added once
                 nb_wave += __popcll(__ballot(barrier));
@@ -1127,8 +1391,10 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             double ldz, kp, f1, xoff;
             one_body(m, z[a], ldz, kp, f1, xoff);
             if (ok[a]) {
-                F[a] = ldz;
-                if (ITH) kin1[a] = kp; else kin1_sum += kp;
+                if (EN) {
+                    F[a] = ldz;
+                    if (ITH) kin1[a] = kp; else kin1_sum += kp;
+                }
                 if (WF) {
                     prod1 *= f1;
                     xoff_sum += xoff;
@@ -1144,7 +1410,14 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         __builtin_amdgcn_sched_barrier(0);
         if (!m.is_ideal) {
             PTab ta;
-            if (trig_ok) {
+            int i0 = a * DUP * G + gl;
+            if (REUSE) {
+                // the entry this lane published in the first pass (ROTCOPY:
+                // the upper copy is the particle itself)
+                const int io = ROTCOPY ? i0 + ge : i0;
+                ta.s = (double)lS[io]; ta.c = (double)lC[io];
+                ta.su = (double)lSU[io]; ta.cu = (double)lCU[io];
+            } else if (trig_ok) {
                 trig_tab_finish(m, trow, ta);
             } else {
                 sincos_halfpi(z[a] * m.two_over_L, ta.s, ta.c);
@@ -1153,8 +1426,12 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             if (NPASS == 1) {
                 t[a % PA].s = (R)ta.s; t[a % PA].c = (R)ta.c;
                 t[a % PA].su = (R)ta.su; t[a % PA].cu = (R)ta.cu;
-                aks[a % PA] = (R)(m.a_long * ta.s);
-                akc[a % PA] = (R)(m.a_long * ta.c);
+                if (EN) {
+                    aks[a % PA] = (R)(m.a_long * ta.s);
+                    akc[a % PA] = (R)(m.a_long * ta.c);
+                } else {
+                    aks[a % PA] = 0; akc[a % PA] = 0;
+                }
                 if (FOURCASE) make_short_tab<R>(m, ta.su, ta.cu, st4[a % PA]);
                 if (TWOCASE) make_short_tab2<R>(m, ta.su, ta.cu, st2[a % PA]);
                 if (ROTCOPY) {
@@ -1166,10 +1443,9 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                     o.kc0 = (R)(m.m_k2 * c0);
                 }
             }
-            int i0 = a * DUP * G + gl;
             // (idle lanes of a padded shape must not write: with two copies
             // their slot is another lane's)
-            if (PAD && gl >= ge) {
+            if (REUSE || (PAD && gl >= ge)) {
             } else if (ROTCOPY) {
                 // upper copy: the particle itself; lower copy (read when the
                 // partner index wraps): the particle one period below
@@ -1208,21 +1484,23 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         const PairConstsT<R> pc = load_pair_consts<R>(m);
         // make the table visible to the other lanes of the wave (one wave owns
         // its groups' LDS region: LDS ops of a wave complete in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!REUSE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         // sums that count every unordered pair once
 #define QMC_TALLY(q, Y, isshort)                                              \
     do {                                                                      \
-        Qall = q_fma(q, q, Qall);                                             \
+        if (EN) Qall = q_fma(q, q, Qall);                                     \
         if (!WAVE_COUNT) ++npair;                                             \
         /* prodL runs over ALL pairs (no else branch, no second compare);   \
            the short factors are divided out once at the end */             \
         if (WF) prodL *= Y;          /* sign dropped at the end */            \
         if (isshort) {                                                        \
             asm volatile("");   /* exec-masked, not selects */                \
-            Qs = q_fma(q, q, Qs);                                             \
+            if (EN) Qs = q_fma(q, q, Qs);                                     \
             if (!WAVE_COUNT) ++nshort;                                        \
             if (WF) prodS *= Y;                                               \
         }                                                                     \
@@ -1247,20 +1525,20 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 PTabT<R> tb;
                 if (NPASS == 1) tb = t[b % PA];
                 else QMC_LOAD_OWN(tb, b);
-                R q, Y; bool sh; unsigned long long shm;
+                R q = 0, Y; bool sh; unsigned long long shm;
                 if (FOURCASE)
-                    pair_core4<ZCLASS, R>(pc, ta, st4[a % PA], aksa, akca,
-                                          (R)z[a], tb, (R)z[b],
-                                          !PAD || (ok[a] && ok[b]), q, Y, sh,
-                                          shm);
+                    pair_core4<ZCLASS, R, EN>(pc, ta, st4[a % PA], aksa, akca,
+                                              (R)z[a], tb, (R)z[b],
+                                              !PAD || (ok[a] && ok[b]), q, Y,
+                                              sh, shm);
                 else
-                    pair_core<ZCLASS, R>(pc, ta, aksa, akca, (R)z[a], tb,
-                                         (R)z[b], !PAD || (ok[a] && ok[b]), q,
-                                         Y, sh, shm);
+                    pair_core<ZCLASS, R, EN>(pc, ta, aksa, akca, (R)z[a], tb,
+                                             (R)z[b], !PAD || (ok[a] && ok[b]),
+                                             q, Y, sh, shm);
                 if (WAVE_COUNT)
                     ns_wave += __popcll(shm);
                 if (!PAD || (ok[a] && ok[b])) {
-                    Fr[a] += q; Fr[b] -= q;
+                    if (EN) { Fr[a] += q; Fr[b] -= q; }
                     QMC_TALLY(q, Y, sh);
                     if (ITH) {
                         R kk = QMC_PAIR_KIN(q, sh);
@@ -1304,25 +1582,26 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 _Pragma("unroll")                                             \
                 for (int a = 0; a < PA; ++a) {                                \
                     constexpr int ao_base = (H) * PA;                         \
-                    R q, Y; bool sh; unsigned long long shm;                 \
+                    R q = 0, Y; bool sh; unsigned long long shm;             \
                     const bool live = !PAD || (ok[ao_base + a] && pok);       \
                     if (ROTCOPY)                                              \
-                        pair_core1<R>(pc, t[a].s, t[a].c,                     \
+                        pair_core1<R, EN>(pc, t[a].s, t[a].c,                 \
                                       os1[ROTCOPY ? a : 0], aks[a], akc[a],   \
                                       pb, gl < (k),                           \
                                       lSU[a * DUP * G + ge + gl],             \
                                       lCU[a * DUP * G + ge + gl], live, q, Y, \
                                       sh, shm);                               \
                     else if (TWOCASE)                                         \
-                        pair_core2<R>(pc, t[a], st2[TWOCASE ? a : 0], aks[a], \
-                                      akc[a], pb, live, q, Y, sh, shm);       \
+                        pair_core2<R, EN>(pc, t[a], st2[TWOCASE ? a : 0],     \
+                                      aks[a], akc[a], pb, live, q, Y, sh,     \
+                                      shm);                                   \
                     else if (FOURCASE)                                        \
-                        pair_core4<ZCLASS, R>(pc, t[a],                       \
+                        pair_core4<ZCLASS, R, EN>(pc, t[a],                   \
                                               st4[FOURCASE ? a : 0], aks[a],  \
                                               akc[a], (R)z[ao_base + a], pb,  \
                                               pz, live, q, Y, sh, shm);       \
                     else                                                      \
-                        pair_core<ZCLASS, R>(pc, t[a], aks[a], akc[a],        \
+                        pair_core<ZCLASS, R, EN>(pc, t[a], aks[a], akc[a],    \
                                              (R)z[ao_base + a], pb, pz, live, \
                                              q, Y, sh, shm);                  \
                     /* G = 64: the lower half of the lanes is bits 0..31 */   \
@@ -1330,8 +1609,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                         ns_wave += __popcll((LAST) ? (shm & 0xffffffffull)    \
                                                    : shm);                    \
                     if (live) {                                               \
-                        Fr[ao_base + a] += q;                                 \
-                        if (!(LAST)) T[b] -= q;                               \
+                        if (EN) Fr[ao_base + a] += q;                         \
+                        if (EN && !(LAST)) T[b] -= q;                         \
                         if (!(LAST) || count_pair) { QMC_TALLY(q, Y, sh); }   \
                         if (ITH) {                                            \
                             R kk = QMC_PAIR_KIN(q, sh);                       \
@@ -1353,7 +1632,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                     QMC_FOLD(prodL, expL);                                    \
                 }                                                             \
             }                                                                 \
-            if (!(LAST)) {                                                    \
+            if (EN && !(LAST)) {                                              \
                 _Pragma("unroll")                                             \
                 for (int b = 0; b < P; ++b) {                                 \
                     if constexpr (ROT_DPP) {                                  \
@@ -1398,7 +1677,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             /* deliver the travelling sums to their owners (lane gl ^ G/2    \
                holds them) and start the next pass from zero */              \
             _Pragma("unroll")                                                 \
-            for (int b = 0; b < P; ++b) {                                     \
+            for (int b = 0; EN && b < P; ++b) {                               \
                 Fr[b] += PAD ? __shfl(T[b], half_src, 64)                     \
                              : __shfl_xor(T[b], G / 2, 64);                   \
                 T[b] = 0;                                                     \
@@ -1426,26 +1705,35 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         int k_first = 1;
         constexpr bool LEAD_SHORT = QMC_LEAD_SHORT && ROTCOPY && (G == 64) &&
                                     !PAD && (P == 1);
-        if constexpr (LEAD_SHORT) {
+        // the log|psi|-only pass has its own loop (logpsi_pairs64)
+        constexpr bool WF_LOOP = QMC_WF_LOOP && LEAD_SHORT && !EN && WF;
+        if constexpr (WF_LOOP) {
+            QMC_SECTION("rotation");
+            logpsi_pairs64<R>(pc, t[0].s, t[0].c, os1[0], gl, lS, lC, lSU, lCU,
+                              prodS, expS, prodL, expL, ns_wave);
+            k_first = G;        // nothing left for the passes below
+        } else if constexpr (LEAD_SHORT) {
             if (pc.sp_ok) {
                 R Q1 = 0, P1 = 1;          // tallies of these steps
                 int e1 = 0;
                 bool lead = true;
 #define QMC_LEAD_TAIL(X, Y)                                                   \
                 {                                                             \
-                    const R q = pair_div(X, Y);                               \
                     ns_wave += 64;                                            \
-                    Fr[0] += q;                                               \
-                    T[0] -= q;                                                \
-                    Q1 = q_fma(q, q, Q1);                                     \
                     if (WF) P1 *= Y;                                          \
-                    if (ITH) {                                                \
-                        const R kk = q_fma(q, q, pc.k2sq);                    \
-                        Kown[0] += kk;                                        \
-                        KT[0] += kk;                                          \
+                    if (EN) {                                                 \
+                        const R q = pair_div(X, Y);                           \
+                        Fr[0] += q;                                           \
+                        T[0] -= q;                                            \
+                        Q1 = q_fma(q, q, Q1);                                 \
+                        if (ITH) {                                            \
+                            const R kk = q_fma(q, q, pc.k2sq);                \
+                            Kown[0] += kk;                                    \
+                            KT[0] += kk;                                      \
+                        }                                                     \
+                        T[0] = group_ror1<G>(T[0]);                           \
+                        if (ITH) KT[0] = group_ror1<G>(KT[0]);                \
                     }                                                         \
-                    T[0] = group_ror1<G>(T[0]);                               \
-                    if (ITH) KT[0] = group_ror1<G>(KT[0]);                    \
                 }
                 QMC_SECTION("leading_neighbour_steps");
                 {
@@ -1460,8 +1748,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                             lead = false;
                             break;
                         }
-                        const R t2 = q_copysign(pc.k2sphi, Su);
-                        const R Xs = q_fma(pc.m_k2cphi, Su, Cu * t2);
+                        R Xs = 0;
+                        if (EN) {
+                            const R t2 = q_copysign(pc.k2sphi, Su);
+                            Xs = q_fma(pc.m_k2cphi, Su, Cu * t2);
+                        }
                         const R Ys = q_fma(q_abs(Su), pc.sphi, Cu * pc.cphi);
                         QMC_LEAD_TAIL(Xs, Ys)
                     }
@@ -1491,7 +1782,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 #undef QMC_LEAD_TAIL
                 // these pairs belong to the tallies of all pairs and of the
                 // short ones
-                Qall += Q1; Qs += Q1;
+                if (EN) { Qall += Q1; Qs += Q1; }
                 if (WF) {
                     QMC_FOLD(P1, e1);
                     prodS *= P1; prodL *= P1;
@@ -1499,22 +1790,25 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 }
             }
         }
-        QMC_SECTION("rotation");
-        QMC_PASS(0)
-        QMC_PASS(1)
-        QMC_PASS(2)
-        QMC_PASS(3)
+        if constexpr (!WF_LOOP) {
+            QMC_SECTION("rotation");
+            QMC_PASS(0)
+            QMC_PASS(1)
+            QMC_PASS(2)
+            QMC_PASS(3)
+        }
 #undef QMC_PASS
 #undef QMC_KSTEP
     }
 #pragma unroll
-    for (int a = 0; a < P; ++a)
+    for (int a = 0; EN && a < P; ++a)
         F[a] = RD ? (double)Fr[a] : F[a] + (double)Fr[a];
 
     // ---- local energy ----
     QMC_SECTION("energy+logwf");
     double e_lane = 0.0;
-    if (ITH) {
+    if (!EN) {
+    } else if (ITH) {
 #pragma unroll
         for (int a = 0; a < P; ++a) {
             double e = ok[a] ? ((double)Kown[a] + kin1[a] - F[a] * F[a]) : 0.0;
@@ -1540,19 +1834,21 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
     // (one particle per lane only: with more, the accumulator registers of the
     // matrix instruction cost the N = 128 DMC step a wave of occupancy, -5 %)
     constexpr bool MSUM = QMC_MFMA_SUM && (G == 64) && (P == 1);
-    if (!MSUM) E = group_sum<G>(e_lane);
+    if (!EN) {
+    } else if (!MSUM) E = group_sum<G>(e_lane);
     else if (!WF) E = wave_sum_mfma(e_lane);
     double e_consts = 0.0;
-    if (WAVE_COUNT && !ITH && nb_counted) {
+    if (!EN) {
+    } else if (WAVE_COUNT && !ITH && nb_counted) {
         // one-body region constants of the n particles, nb_wave in a barrier
         e_consts += (double)(n - nb_wave) * m.e0 +
                     (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
     }
-    if (WAVE_COUNT && !ITH && !m.is_ideal) {
+    if (EN && WAVE_COUNT && !ITH && !m.is_ideal) {
         int nl_wave = n * (n - 1) / 2 - ns_wave;
         e_consts += 2.0 * (m.k2sq * (double)ns_wave + m.b_long * (double)nl_wave);
     }
-    if (!(MSUM && WF)) E += e_consts;
+    if (EN && !(MSUM && WF)) E += e_consts;
     if (WF) {
         const double LN2 = 0.693147180559945309417;
         // prodL holds every pair's |Y|, prodS the short ones (cos > 0):
@@ -1572,9 +1868,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         lw += LN2 * ((double)(expS + exp1) + m.beta * (double)(expL - expS)) -
               xoff_sum;
         if (!WAVE_COUNT) lw += (double)nshort * m.log_am;
-        if (MSUM) {
+        if (MSUM && EN) {
             wave_sum2_mfma(e_lane, lw, E, logwf);
             E += e_consts;
+        } else if (MSUM) {
+            logwf = wave_sum_mfma(lw);
         } else {
             logwf = group_sum<G>(lw);
         }

@@ -5,8 +5,25 @@
 #pragma once
 
 #include "qmc_device.h"
+#include "qmc_sorted64.h"
 
 static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
+
+// Workgroup size of the walker kernels.  One walker per wavefront (G = 64):
+// ONE wavefront per workgroup.  A workgroup's slots are released when its last
+// wavefront ends, and the wavefronts of the VMC step do not take equally long
+// (an accepted move runs the energy pass, a rejected one does not): with four
+// per workgroup 1 - 0.52^4 = 93 % of the workgroups last as long as an accepted
+// move and the two-pass step gains nothing (measured: 10 % fewer busy vector
+// cycles, 5 % MORE time); with one, a slot is free again as soon as its chain is
+// done.  The kernels synchronise inside a wavefront only, so the size is free.
+#ifndef QMC_BLOCK64
+#define QMC_BLOCK64 64
+#endif
+template <int G>
+struct WalkBlock {
+    static constexpr int N = (G == 64) ? QMC_BLOCK64 : BLOCK;
+};
 
 // a wave-uniform 64-bit value as the compiler can see it (scalar registers)
 __device__ __forceinline__ long long qmc_uniform(long long v)
@@ -34,6 +51,16 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
 #define QMC_LB_WAVES_VMC , ((G == 64 && P == 1) ? QMC_LB_P1 \
                             : (G == 64 && P == 2 && !PAD) ? QMC_LB_VMC_P2 : 1)
 
+// The VMC step in two passes (one wavefront per walker: the accept decision
+// is wave-uniform): log|psi| of the proposal first -- no quotient, no drift --
+// then, for accepted moves only, energy and drift from the pair tables still in
+// LDS.  The reference computes the energy of accepted moves only as well
+// (qmc_base/jastrow/vmc.py:253-262); a rejected proposal (53 % at the benchmark's
+// move spread) pays for log|psi| alone.
+#ifndef QMC_VMC_TWO_PASS
+#define QMC_VMC_TWO_PASS 1
+#endif
+
 // odd-even transposition passes (resort_step) run every this many steps
 #ifndef QMC_RESORT_EVERY
 #define QMC_RESORT_EVERY 4
@@ -48,14 +75,15 @@ struct EvalArgs {
 };
 
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
+__global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES)
 evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the
     // SGPR file free for the hot loop (by-value they overflow it)
     const DevModel &m = *mp;
+    QMC_SECTION("top");
     extern __shared__ double smem[];
-    constexpr int GPB = BLOCK / G;            // groups per block
+    constexpr int GPB = WalkBlock<G>::N / G;            // groups per block
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
     const long long w = (long long)blockIdx.x * GPB + grp;
@@ -92,14 +120,15 @@ struct PrepArgs {
 };
 
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
+__global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES)
 prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the
     // SGPR file free for the hot loop (by-value they overflow it)
     const DevModel &m = *mp;
+    QMC_SECTION("top");
     extern __shared__ double smem[];
-    constexpr int GPB = BLOCK / G;
+    constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
     const long long w = (long long)blockIdx.x * GPB + grp;
@@ -154,12 +183,13 @@ struct VmcArgs {
 // only); the full variant adds the test-only tape replay, the Gaussian
 // proposal and the per-step series.
 template <int G, int P, bool PAD, bool ZC, bool LEAN, typename R = double>
-__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES_VMC)
+__global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES_VMC)
 vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 {
     const DevModel &m = *mp;
+    QMC_SECTION("top");
     extern __shared__ double smem[];
-    constexpr int GPB = BLOCK / G;
+    constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
     const long long w = (long long)blockIdx.x * GPB + grp;
@@ -221,7 +251,13 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     QMC_SECTION("resort");
     // (one odd-even pass every QMC_RESORT_EVERY steps keeps the lanes sorted
     // well enough: a particle moves a few per cent of the spacing per step)
-    if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
+    // exactly ascending lanes: the fast pair sum of qmc_sorted64.h
+    constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !PAD && !ZC;
+    bool fast = false;
+    if constexpr (S64) {
+        fast = !m.is_ideal && sort_lanes64(zn[0], labn[0], gl) &&
+               far_partner_ok64(m, zn[0], gl);
+    } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         // ascending order, wrap point anchored at the lane seam (qmc_device.h)
         // (one particle per lane: lanes 0 .. n-1 hold them)
         if (!forced) {
@@ -239,9 +275,18 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     } else if (!forced && (a.step % QMC_RESORT_EVERY) == 0)
         resort_step<G, P>(zn, labn, gl, a.step / QMC_RESORT_EVERY, n, m.L,
                           m.half_L, lanes_in_use<G, PAD>(m));
-    double F[P], ei[P], e_new, wf_new;
-    eval_walker<G, P, PAD, true, false, ZC, R>(m, zn, gl, lds, F, ei, e_new,
-                                               wf_new);
+    constexpr bool TWO_PASS = QMC_VMC_TWO_PASS && (G == 64);
+    double F[P], ei[P], e_new = 0.0, wf_new;
+    if (S64 && fast) {
+        if constexpr (S64)
+            eval_sorted64<R, true, !TWO_PASS, false>(m, zn[0], gl, lds, F[0],
+                                                     e_new, wf_new);
+    } else if constexpr (TWO_PASS)
+        eval_walker<G, P, PAD, true, false, ZC, R, false, false>(
+            m, zn, gl, lds, F, ei, e_new, wf_new);
+    else
+        eval_walker<G, P, PAD, true, false, ZC, R>(m, zn, gl, lds, F, ei,
+                                                   e_new, wf_new);
     QMC_SECTION("metropolis+store");
     if (!forced) {
         if (!LEAN && a.tape) {
@@ -276,7 +321,23 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // wavefront owns one chain)
     bool acc = forced || ua <= 0.0 || wf_new > wf_cur;
     if (!acc) acc = wf_new > 0.5 * log_pos(ua) + wf_cur;
+    // (one chain per wavefront: every lane holds the same decision)
+    if (G == 64) acc = __builtin_amdgcn_readfirstlane((int)acc) != 0;
     if (acc) {
+        if constexpr (TWO_PASS) {
+            QMC_SECTION("energy_pass");
+            QMC_SECTION_PHASE(QMC_NSEC / 2);
+            double wf_unused;
+            if (S64 && fast) {
+                if constexpr (S64)
+                    eval_sorted64<R, false, true, true>(m, zn[0], gl, lds, F[0],
+                                                        e_new, wf_unused);
+            } else
+                eval_walker<G, P, PAD, false, false, ZC, R, true, true>(
+                    m, zn, gl, lds, F, ei, e_new, wf_unused);
+            QMC_SECTION_PHASE(0);
+            QMC_SECTION("store");
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = lane_particle<G, P, PAD>(m, gl, p);
@@ -316,6 +377,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             if (a.ser_stat) a.ser_stat[a.y * a.W + w] = acc ? 1 : 0;
         }
     }
+    QMC_SECTION("end");
 }
 
 // ---- DMC ---------------------------------------------------------------
@@ -351,20 +413,21 @@ struct EvolveArgs {
 // Drift-diffusion + local energy of every child walker
 // (qmc_base/jastrow/dmc.py:758-825, 892-942).
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(BLOCK QMC_LB_WAVES)
+__global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES)
 dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the
     // SGPR file free for the hot loop (by-value they overflow it)
     const DevModel &m = *mp;
     extern __shared__ double smem[];
-    constexpr int GPB = BLOCK / G;
+    constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
     const long long s = (long long)blockIdx.x * GPB + grp;
     const long long nw = a.ctl->nw;
     // whole block beyond the population: nothing to do
     if ((long long)blockIdx.x * GPB >= nw) return;
+    QMC_SECTION("top");
     const bool active = s < nw;
     const long long sr = active ? s : 0;
     const int n = m.n;
@@ -383,6 +446,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         e_slot = a.eslot[su];
     }
 
+    QMC_SECTION("load+philox+wrap");
     double z[P];
     int lab[P];
 #pragma unroll
@@ -417,7 +481,13 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         }
         z[p] = zz;
     }
-    if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
+    QMC_SECTION("resort");
+    constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !PAD && !ZC;
+    bool fast = false;
+    if constexpr (S64) {
+        fast = !m.is_ideal && sort_lanes64(z[0], lab[0], gl) &&
+               far_partner_ok64(m, z[0], gl);
+    } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         anchor_seam(z[0], lab[0], n);
         if ((step % QMC_RESORT_EVERY) == 0)
             resort_linear<G>(z[0], lab[0], gl, step / QMC_RESORT_EVERY, n);
@@ -438,8 +508,14 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         }
     }
     double F[P], ei[P], e_next, wf;
-    eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei, e_next,
-                                                wf);
+    if (S64 && fast) {
+        if constexpr (S64)
+            eval_sorted64<R, false, true, false>(m, z[0], gl, lds, F[0], e_next,
+                                                 wf);
+    } else
+        eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei,
+                                                    e_next, wf);
+    QMC_SECTION("weight+store");
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -456,4 +532,5 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         a.cweight[s] = exp(-a.dt * (mean_energy - ref_energy));
         a.eslot[s] = e_par;
     }
+    QMC_SECTION("end");
 }

@@ -1,0 +1,311 @@
+// qmc_sorted64.h -- the pair sum of the benchmark shape (one walker per
+// wavefront, one particle per lane, N = 64, pairs classified from the sines)
+// on lanes held in EXACTLY ascending position.
+//
+// Why a second path.  PMC + micro-benchmarks of round 3 (profiles/r03_*): on
+// gfx950 the scalar pipe issues one instruction per ~4.2 cycles and SIMD, the
+// same as the fp64 vector pipe, and the two overlap only as far as the eight
+// wavefronts of a SIMD happen to want different pipes.  The rotation loop of
+// eval_walker executes 26-28 scalar instructions and branches per step next to
+// 14-23 vector ones -- exec-mask regions, validity tests of the "leading
+// steps", fold checks, short-pair counts, loop control -- and the kernel sat at
+// vector 94 % / scalar 53-68 % busy with every instruction removed from one
+// pipe reappearing as queueing behind the other.  The validity tests exist
+// because the lanes were only approximately ordered (one transposition pass
+// every fourth step).  With the lanes exactly ascending, and the lower copy of
+// the LDS tables holding the particles one period below (pair_core1), the
+// separation D'_k = z_lane - z'_(lane-k) seen at rotation step k is >= 0 and
+// grows with k for every lane.  Hence, with D'_(G/2) < L - rm checked once per
+// walker (no pair is short through the periodic image on the far side):
+//   * a pair is short iff D' < rm, always in the single (unwrapped, ordered)
+//     case: no generic branch, no sign tests;
+//   * the leading steps need ONE compare per step (partner position against
+//     z - rm) instead of three plus a scalar reduction;
+//   * |a_m| is folded into the own short-range table, so log|psi| needs no
+//     count of short pairs.
+// The loops request the partner's tables one step ahead: a step is 4-15 vector
+// instructions, too few to hide an LDS round trip behind.
+// Walkers that fail the once-per-walker checks (practically never: it takes 32
+// particles inside L/4) take eval_walker, which is exact for any order.
+#pragma once
+
+#include "qmc_device.h"
+
+#ifndef QMC_SORTED64
+#define QMC_SORTED64 1
+#endif
+
+// lane i takes the value of lane i - 1 (lane 0 keeps its own)
+__device__ __forceinline__ double wave_shr1_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(
+        __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false),
+        __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false));
+}
+
+// true iff the 64 lanes hold ascending positions (wave-uniform)
+__device__ __forceinline__ bool lanes_ascending64(double z)
+{
+    return __builtin_amdgcn_ballot_w64(z < wave_shr1_f64(z)) == 0ull;
+}
+
+// Odd-even transposition passes until the lanes are ascending (a VMC / DMC move
+// displaces a particle by a few per cent of the spacing: most steps need none
+// or one double pass).  `anchor_seam` first: a particle that crossed the box
+// boundary sits at the wrong end of the row and is rotated into place instead
+// of being bubbled through 63 lanes.  Bounded: odd-even transposition sorts n
+// items in n passes.
+__device__ __forceinline__ bool sort_lanes64(double &z, int &lab, int gl)
+{
+    for (int it = 0; it < 34; ++it) {
+        anchor_seam(z, lab, 64);
+        if (lanes_ascending64(z)) return true;
+        resort_linear<64>(z, lab, gl, 0u, 64);
+        resort_linear<64>(z, lab, gl, 1u, 64);
+    }
+    return lanes_ascending64(z);
+}
+
+// The once-per-walker condition beside the order: the farthest partner of the
+// rotation (step G/2, lane ^ 32) is closer than L - rm, i.e. no pair of the 32
+// steps is short-range through the image on the far side.
+__device__ __forceinline__ bool far_partner_ok64(const DevModel &m, double z,
+                                                 int gl)
+{
+    const double zp = __shfl_xor(z, 32, 64);
+    // D' = z - zp for the upper half of the lanes, z - (zp - L) for the lower
+    const double d = (gl < 32) ? (z - zp) + m.L : z - zp;
+    return __builtin_amdgcn_ballot_w64(d >= m.L_minus_rm) == 0ull;
+}
+
+template <typename R>
+struct Own64 {
+    R s, c;          // sin, cos(pi z / L)
+    R aks, akc;      // a_long times them (long-range numerator)
+    R s0, c0;        // |a_m| sin, cos(k2 z - phi): Y = f2 itself for a short pair
+    R ks0, kc0;      // -k2 times them (short-range numerator)
+    R zt;            // z - rm: a partner above it is closer than rm
+};
+
+// One walker on ascending lanes.  z: the lane's particle; lds: 5 rows of 2 G
+// entries (sin, cos(pi z / L), sin, cos(k2 z), z; upper copy = the particle,
+// lower copy = the particle one period below).
+//   WF    : logwf out;   EN: E and F (drift of the lane's particle) out
+//   REUSE : the tables of this configuration are already in LDS
+template <typename R, bool WF, bool EN, bool REUSE>
+__device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int gl,
+                                              double *lds, double &F, double &E,
+                                              double &logwf)
+{
+    constexpr int G = 64, ROW = 2 * G;
+    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
+      *lZ = lS + 4 * ROW;
+    QMC_SECTION("tables+onebody");
+    // ---- one-body factor (as in eval_walker) ----
+    double ldz = 0.0;            // f1'/f1
+    double kin1 = 0.0;           // -f1''/f1 + ldz^2 + V (or ldz^2 alone, below)
+    double xoff = 0.0;           // -log f1 (WF)
+    double prod1 = 1.0;          // f1 itself on the direct path (WF)
+    int nb_wave = 0;             // particles inside a barrier (uniform barriers)
+    bool nb_counted = false;
+    TrigRow trow;
+    const bool trig_ok = !REUSE && m.trig_table && trig_tab_load(m, z, trow);
+    if (!m.is_free && m.ob_table) {
+        double lf = 0.0;
+        bool barrier;
+        one_body_tab<WF, EN>(m, z, ldz, lf, barrier);
+        if (WF) xoff = -lf;
+        if (EN) {
+            if (m.uniform_barrier) {
+                nb_wave = __popcll(__ballot(barrier));
+                nb_counted = true;
+                kin1 = ldz * ldz;
+            } else {
+                kin1 = fma(ldz, ldz, one_body_kin_const(m, z, barrier));
+            }
+        }
+    } else if (!m.is_free) {
+        double kp, f1, xo;
+        one_body(m, z, ldz, kp, f1, xo);
+        if (EN) kin1 = kp;
+        if (WF) { prod1 = f1; xoff = xo; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- pair tables ----
+    Own64<R> o;
+    {
+        PTab ta;
+        if (REUSE) {
+            ta.s = (double)lS[G + gl]; ta.c = (double)lC[G + gl];
+            ta.su = (double)lSU[G + gl]; ta.cu = (double)lCU[G + gl];
+        } else if (trig_ok) {
+            trig_tab_finish(m, trow, ta);
+        } else {
+            sincos_halfpi(z * m.two_over_L, ta.s, ta.c);
+            sincos_halfpi(z * m.k2_2pi, ta.su, ta.cu);
+        }
+        o.s = (R)ta.s; o.c = (R)ta.c;
+        if (EN) {
+            o.aks = (R)(m.a_long * ta.s);
+            o.akc = (R)(m.a_long * ta.c);
+        }
+        const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
+        const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
+        o.s0 = (R)s0; o.c0 = (R)c0;
+        if (EN) {
+            o.ks0 = (R)(m.m_k2 * s0);
+            o.kc0 = (R)(m.m_k2 * c0);
+        }
+        o.zt = (R)(z - m.rm);
+        if (!REUSE) {
+            lS[G + gl] = (R)ta.s; lC[G + gl] = (R)ta.c;
+            lSU[G + gl] = (R)ta.su; lCU[G + gl] = (R)ta.cu;
+            lZ[G + gl] = (R)z;
+            lS[gl] = (R)-ta.s; lC[gl] = (R)-ta.c;
+            lSU[gl] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
+            lCU[gl] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
+            lZ[gl] = (R)(z - m.L);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    const R sin_rm = (R)m.sin_rm;
+    // partner of rotation step k: entry (G + gl) - k
+    const R *pS = lS + G + gl, *pC = lC + G + gl, *pSU = lSU + G + gl,
+            *pCU = lCU + G + gl, *pZ = lZ + G + gl;
+
+    R Fr = (R)ldz;           // drift: one-body term + pair quotients
+    R T = 0;                 // travelling sum for the partner lane
+    R Qall = 0, Qs = 0;      // sum of q^2 over all / short pairs
+    R PS = 1, PL = 1;        // products: short factors f2, |Y| of all pairs
+    int eS = 0, eL = 0;      // their binary exponents (float pair loop)
+    int ns = 0;              // short pairs (EN: region constants of the energy)
+    int k = 1;
+
+    // ---- leading steps: every lane's partner is closer than rm ----
+    QMC_SECTION("leading_short_steps");
+    {
+        R nsu = pSU[-1], ncu = pCU[-1], nz = pZ[-1];
+        // (two steps per trip: the copies of the requested tables into the
+        // current ones disappear into the register allocation; fully unrolled
+        // -- the trip count is a constant -- the kernel is 25 KB and every exit
+        // walks a chain of moves)
+#pragma clang loop unroll_count(2)
+        for (; k < G / 2; ++k) {
+            const R bsu = nsu, bcu = ncu, bz = nz;
+            // the next step's partner (k + 1 <= G/2: inside the tables)
+            nsu = pSU[-(k + 1)]; ncu = pCU[-(k + 1)]; nz = pZ[-(k + 1)];
+            if (__builtin_amdgcn_ballot_w64(bz > o.zt) != ~0ull) break;
+            const R Y = o.c0 * bcu + o.s0 * bsu;      // f2 = |a_m| cos(k2 D' - phi)
+            if (WF) PS *= Y;
+            if (EN) {
+                const R X = o.ks0 * bcu - o.kc0 * bsu;
+                const R q = pair_div(X, Y);
+                Fr += q;
+                T -= q;
+                Qs = q_fma(q, q, Qs);
+                T = group_ror1<G>(T);
+            }
+            if (WF && sizeof(R) == 4 && (k & 7) == 0) q_fold(PS, eS);
+        }
+    }
+    // (these pairs belong to both products and both sums)
+    if (WF) { PL = PS; eL = eS; }
+    if (EN) { Qall = Qs; ns = (k - 1) * G; }
+
+    // ---- general steps: classified pair by pair ----
+    QMC_SECTION("rotation_loop_body");
+#define QMC_S64_STEP(LAST)                                                    \
+    {                                                                         \
+        const R S = o.s * cc - o.c * cs;       /* sin(pi D' / L) > 0 */        \
+        R X = 0;                                                              \
+        if (EN) X = o.akc * cc + o.aks * cs;   /* a_long cos(pi D' / L) */     \
+        const bool mine = !(LAST) || gl < G / 2;                              \
+        const bool sh = q_abs(S) < sin_rm;     /* D' < rm */                   \
+        if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));       \
+        R Y = S;                                                              \
+        if (sh) {                                                             \
+            asm volatile("");                  /* exec-masked, not selects */  \
+            const R bsu = pSU[-k], bcu = pCU[-k];                             \
+            Y = o.c0 * bcu + o.s0 * bsu;                                      \
+            if (EN) X = o.ks0 * bcu - o.kc0 * bsu;                            \
+            if (WF && mine) PS *= Y;                                          \
+        }                                                                     \
+        if (WF && mine) PL *= Y;                                              \
+        if (EN) {                                                             \
+            const R q = pair_div(X, Y);                                       \
+            Fr += q;                                                          \
+            if (!(LAST)) {                                                    \
+                T -= q;                                                       \
+                T = group_ror1<G>(T);                                         \
+            }                                                                 \
+            if (mine) {                                                       \
+                Qall = q_fma(q, q, Qall);                                     \
+                if (sh) {                                                     \
+                    asm volatile("");                                         \
+                    Qs = q_fma(q, q, Qs);                                     \
+                }                                                             \
+            }                                                                 \
+        }                                                                     \
+    }
+    {
+        R bs = pS[-k], bc = pC[-k];
+#pragma clang loop unroll_count(2)
+        for (; k < G / 2; ++k) {
+            const R cs = bs, cc = bc;
+            bs = pS[-(k + 1)]; bc = pC[-(k + 1)];
+            QMC_S64_STEP(false)
+            if (WF && sizeof(R) == 4 && (k & 7) == 0) {
+                q_fold(PS, eS);
+                q_fold(PL, eL);
+            }
+        }
+        // the final half step visits every pair from both sides: each side
+        // updates its own particle, the lower half of the lanes tallies
+        QMC_SECTION("rotation_last_step");
+        const R cs = bs, cc = bc;
+        QMC_S64_STEP(true)
+    }
+#undef QMC_S64_STEP
+    if (EN) Fr += __shfl_xor(T, G / 2, 64);
+
+    QMC_SECTION("energy+logwf");
+    double e_lane = 0.0, e_consts = 0.0;
+    if (EN) {
+        F = (double)Fr;
+        const double Qall_d = (double)Qall, Qs_d = (double)Qs;
+        const double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
+        e_lane = fma(2.0, pk, kin1) - F * F;
+        if (nb_counted)
+            e_consts += (double)(G - nb_wave) * m.e0 +
+                        (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
+        const int nl = G * (G - 1) / 2 - ns;
+        e_consts += 2.0 * (m.k2sq * (double)ns + m.b_long * (double)nl);
+    }
+    double lw = 0.0;
+    if (WF) {
+        const double LN2 = 0.693147180559945309417;
+        const double PS_d = (double)PS, PL_d = (double)PL;
+        if (!m.is_free && m.ob_table) {
+            const double lSv = log_pos(PS_d);
+            lw = fma(m.beta, log_pos(PL_d) - lSv, lSv);
+        } else {
+            lw = log_pos(prod1 * PS_d) +
+                 m.beta * log_pos(fast_div(PL_d, PS_d));
+        }
+        if (sizeof(R) == 4)
+            lw += LN2 * ((double)eS + m.beta * (double)(eL - eS));
+        lw -= xoff;
+    }
+    if (WF && EN) {
+        wave_sum2_mfma(e_lane, lw, E, logwf);
+        E += e_consts;
+    } else if (EN) {
+        E = wave_sum_mfma(e_lane) + e_consts;
+    } else {
+        logwf = wave_sum_mfma(lw);
+    }
+}

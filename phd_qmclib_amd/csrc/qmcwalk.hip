@@ -52,6 +52,7 @@ struct qmc_engine {
     DevModel *dm_dev = nullptr;
     double *ob_table_dev = nullptr;     // one-body table rows (or null)
     double *trig_table_dev = nullptr;   // pair-angle row table (or null)
+    unsigned long long *sec_prof_dev = nullptr;  // QMC_TIMING builds only
     qmc_model_params mp;
     int G = 64, P = 1;
     bool pad = false;
@@ -147,7 +148,8 @@ static int dispatch_shape(const qmc_engine *e, A &&...args)
 template <int G, int P, bool ZC>
 static size_t lds_bytes()
 {
-    return (size_t)(BLOCK / G) * GroupLds<G, P, ZC>::DOUBLES * sizeof(double);
+    return (size_t)(WalkBlock<G>::N / G) * GroupLds<G, P, ZC>::DOUBLES *
+           sizeof(double);
 }
 
 // Dynamic LDS above the default limit must be opted into per kernel.
@@ -163,7 +165,7 @@ static void allow_lds(K kernel, size_t bytes)
 template <int G>
 static unsigned grid_for(long long nwalkers)
 {
-    const long long gpb = BLOCK / G;
+    const long long gpb = WalkBlock<G>::N / G;
     return (unsigned)((nwalkers + gpb - 1) / gpb);
 }
 
@@ -183,7 +185,7 @@ struct LaunchEval {
             if (e->fast) {
                 allow_lds(evaluate_kernel<G, P, PAD, ZC, float>, lds);
                 hipLaunchKernelGGL((evaluate_kernel<G, P, PAD, ZC, float>),
-                                   dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                                   dim3(grid_for<G>(a.nconf)), dim3(WalkBlock<G>::N),
                                    lds, e->stream, e->dm_dev, a);
                 HIP_TRY(hipGetLastError());
                 return 0;
@@ -191,7 +193,7 @@ struct LaunchEval {
         }
         allow_lds(evaluate_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((evaluate_kernel<G, P, PAD, ZC>),
-                           dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                           dim3(grid_for<G>(a.nconf)), dim3(WalkBlock<G>::N),
                            lds, e->stream, e->dm_dev, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -209,7 +211,7 @@ struct LaunchPrep {
             if (e->fast) {
                 allow_lds(prepare_kernel<G, P, PAD, ZC, float>, lds);
                 hipLaunchKernelGGL((prepare_kernel<G, P, PAD, ZC, float>),
-                                   dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                                   dim3(grid_for<G>(a.nconf)), dim3(WalkBlock<G>::N),
                                    lds, e->stream, e->dm_dev, a);
                 HIP_TRY(hipGetLastError());
                 return 0;
@@ -217,7 +219,7 @@ struct LaunchPrep {
         }
         allow_lds(prepare_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((prepare_kernel<G, P, PAD, ZC>),
-                           dim3(grid_for<G>(a.nconf)), dim3(BLOCK),
+                           dim3(grid_for<G>(a.nconf)), dim3(WalkBlock<G>::N),
                            lds, e->stream, e->dm_dev, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -239,14 +241,14 @@ struct LaunchVmc {
                     allow_lds(vmc_step_kernel<G, P, PAD, ZC, true, float>, lds);
                     hipLaunchKernelGGL(
                         (vmc_step_kernel<G, P, PAD, ZC, true, float>),
-                        dim3(grid_for<G>(a.W)), dim3(BLOCK), lds, e->stream,
+                        dim3(grid_for<G>(a.W)), dim3(WalkBlock<G>::N), lds, e->stream,
                         e->dm_dev, a);
                 } else {
                     allow_lds(vmc_step_kernel<G, P, PAD, ZC, false, float>,
                               lds);
                     hipLaunchKernelGGL(
                         (vmc_step_kernel<G, P, PAD, ZC, false, float>),
-                        dim3(grid_for<G>(a.W)), dim3(BLOCK), lds, e->stream,
+                        dim3(grid_for<G>(a.W)), dim3(WalkBlock<G>::N), lds, e->stream,
                         e->dm_dev, a);
                 }
                 HIP_TRY(hipGetLastError());
@@ -256,12 +258,12 @@ struct LaunchVmc {
         if (lean) {
             allow_lds(vmc_step_kernel<G, P, PAD, ZC, true>, lds);
             hipLaunchKernelGGL((vmc_step_kernel<G, P, PAD, ZC, true>),
-                               dim3(grid_for<G>(a.W)), dim3(BLOCK), lds,
+                               dim3(grid_for<G>(a.W)), dim3(WalkBlock<G>::N), lds,
                                e->stream, e->dm_dev, a);
         } else {
             allow_lds(vmc_step_kernel<G, P, PAD, ZC, false>, lds);
             hipLaunchKernelGGL((vmc_step_kernel<G, P, PAD, ZC, false>),
-                               dim3(grid_for<G>(a.W)), dim3(BLOCK), lds,
+                               dim3(grid_for<G>(a.W)), dim3(WalkBlock<G>::N), lds,
                                e->stream, e->dm_dev, a);
         }
         HIP_TRY(hipGetLastError());
@@ -282,7 +284,7 @@ struct LaunchEvolve {
             if (e->fast) {
                 allow_lds(dmc_evolve_kernel<G, P, PAD, ZC, float>, lds);
                 hipLaunchKernelGGL((dmc_evolve_kernel<G, P, PAD, ZC, float>),
-                                   dim3(grid_for<G>(a.maxw)), dim3(BLOCK),
+                                   dim3(grid_for<G>(a.maxw)), dim3(WalkBlock<G>::N),
                                    lds, e->stream, e->dm_dev, a);
                 HIP_TRY(hipGetLastError());
                 return 0;
@@ -290,7 +292,7 @@ struct LaunchEvolve {
         }
         allow_lds(dmc_evolve_kernel<G, P, PAD, ZC>, lds);
         hipLaunchKernelGGL((dmc_evolve_kernel<G, P, PAD, ZC>),
-                           dim3(grid_for<G>(a.maxw)), dim3(BLOCK),
+                           dim3(grid_for<G>(a.maxw)), dim3(WalkBlock<G>::N),
                            lds, e->stream, e->dm_dev, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -316,6 +318,8 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     double phi = p.param_k2 * p.param_r_off;
     d.cphi = cos(phi);
     d.sphi = sin(phi);
+    d.am_cphi = fabs(p.param_am) * d.cphi;
+    d.am_sphi = fabs(p.param_am) * d.sphi;
     d.m_k2cphi = -d.k2 * d.cphi;
     d.k2sphi = d.k2 * d.sphi;
     double th = p.param_k2 * d.L;
@@ -637,6 +641,13 @@ static int engine_create_impl(const qmc_model_params *model, int device,
             e->dm.trig_table = e->trig_table_dev;
         }
     }
+#if defined(QMC_TIMING)
+    HIP_TRY(hipMalloc((void **)&e->sec_prof_dev, (size_t)QMC_SEC_COPIES * 2 *
+                      QMC_NSEC * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e->sec_prof_dev, 0, (size_t)QMC_SEC_COPIES * 2 *
+                      QMC_NSEC * sizeof(unsigned long long)));
+    e->dm.sec_prof = e->sec_prof_dev;
+#endif
     HIP_TRY(hipMalloc((void **)&e->dm_dev, sizeof(DevModel)));
     HIP_TRY(hipMemcpy(e->dm_dev, &e->dm, sizeof(DevModel),
                       hipMemcpyHostToDevice));
@@ -829,6 +840,50 @@ extern "C" int qmc_engine_profile_end(qmc_engine *e, int64_t *launches,
     return 0;
 }
 
+// Diagnostic libraries built with -DQMC_TIMING (tools/section_times.py): cycles
+// of wavefront lifetime and visits per kernel section since the last reset,
+// summed over every walker kernel launched on this engine.  Section i of the
+// first pass of a kernel is qmc_section_name(i); i + nsec / 2 is the same
+// section inside the energy pass of the VMC step.  The shipped library has no
+// stamps in its kernels and returns an error here.
+extern "C" int qmc_engine_section_profile(qmc_engine *e, uint64_t *cycles,
+                                          uint64_t *visits, int32_t nsec,
+                                          int32_t reset)
+{
+    if (!e) return fail("qmc_engine_section_profile: null engine");
+#if defined(QMC_TIMING)
+    if (nsec != QMC_NSEC)
+        return fail("qmc_engine_section_profile: nsec must be 32");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<unsigned long long> host((size_t)QMC_SEC_COPIES * 2 * QMC_NSEC);
+    const size_t bytes = host.size() * sizeof(unsigned long long);
+    HIP_TRY(hipMemcpy(host.data(), e->sec_prof_dev, bytes,
+                      hipMemcpyDeviceToHost));
+    for (int i = 0; i < QMC_NSEC; ++i) {
+        unsigned long long c = 0, v = 0;
+        for (int k = 0; k < QMC_SEC_COPIES; ++k) {
+            c += host[(size_t)k * 2 * QMC_NSEC + i];
+            v += host[(size_t)k * 2 * QMC_NSEC + QMC_NSEC + i];
+        }
+        if (cycles) cycles[i] = c;
+        if (visits) visits[i] = v;
+    }
+    if (reset) HIP_TRY(hipMemset(e->sec_prof_dev, 0, bytes));
+    return 0;
+#else
+    (void)cycles; (void)visits; (void)nsec; (void)reset;
+    return fail("qmc_engine_section_profile: this library was built without "
+                "-DQMC_TIMING (see tools/section_times.py)");
+#endif
+}
+
+extern "C" const char *qmc_section_name(int32_t i)
+{
+    if (i < 0 || i >= QMC_NSEC) return "";
+    return QMC_SEC_NAMES[i % (QMC_NSEC / 2)];
+}
+
 extern "C" void qmc_engine_destroy(qmc_engine *e)
 {
     if (!e) return;
@@ -839,6 +894,7 @@ extern "C" void qmc_engine_destroy(qmc_engine *e)
     if (e->dm_dev) hipFree(e->dm_dev);
     if (e->ob_table_dev) hipFree(e->ob_table_dev);
     if (e->trig_table_dev) hipFree(e->trig_table_dev);
+    if (e->sec_prof_dev) hipFree(e->sec_prof_dev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }

@@ -169,6 +169,26 @@ class ModelEngine:
                                                C.byref(mx)))
         return int(n.value), float(tot.value), float(mn.value), float(mx.value)
 
+    def section_profile(self, reset: bool = True):
+        """Diagnostic libraries only (built with -DQMC_TIMING,
+        tools/section_times.py): {section name: (cycles, visits)} of wavefront
+        lifetime per kernel section since the last reset; names ending in
+        '@energy' are the sections inside the energy pass of the VMC step.
+        Raises with the shipped library."""
+        nsec = 32
+        cyc = (C.c_uint64 * nsec)()
+        vis = (C.c_uint64 * nsec)()
+        check(self._lib.qmc_engine_section_profile(self._h, cyc, vis, nsec,
+                                                   int(reset)))
+        out = {}
+        for i in range(nsec):
+            if vis[i]:
+                name = self._lib.qmc_section_name(i).decode()
+                if i >= nsec // 2:
+                    name += '@energy'
+                out[name] = (int(cyc[i]), int(vis[i]))
+        return out
+
     def close(self):
         if getattr(self, '_h', None):
             self._lib.qmc_engine_destroy(self._h)
