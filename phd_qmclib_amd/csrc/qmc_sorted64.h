@@ -34,6 +34,9 @@
 #ifndef QMC_SORTED64
 #define QMC_SORTED64 1
 #endif
+#ifndef QMC_LDS_AHEAD
+#define QMC_LDS_AHEAD 0
+#endif
 
 // lane i takes the value of lane i - 1 (lane 0 keeps its own)
 __device__ __forceinline__ double wave_shr1_f64(double v)
@@ -50,6 +53,26 @@ __device__ __forceinline__ bool lanes_ascending64(double z)
     return __builtin_amdgcn_ballot_w64(z < wave_shr1_f64(z)) == 0ull;
 }
 
+// One compare-exchange pass: every lane against the lane at byte address
+// `addr` (its partner of the pass, or itself), the lower lane of a pair keeping
+// the smaller position.  `flip` is the sign bit for the upper lanes: with
+// d = z_partner - z, the lower lane takes the partner's particle if d < 0, the
+// upper one if d > 0, i.e. if -d < 0.  (6 vector instructions and 3
+// ds_bpermute; written with a select per lane it compiled to 20.)
+__device__ __forceinline__ void cmpxchg_pass64(double &z, int &lab, int addr,
+                                               int flip)
+{
+    const int plo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(z));
+    const int phi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(z));
+    const int pl = __builtin_amdgcn_ds_bpermute(addr, lab);
+    const double zp = __hiloint2double(phi, plo);
+    const double d = zp - z;
+    const bool take = __hiloint2double(__double2hiint(d) ^ flip,
+                                       __double2loint(d)) < 0.0;
+    z = take ? zp : z;
+    lab = take ? pl : lab;
+}
+
 // Odd-even transposition passes until the lanes are ascending (a VMC / DMC move
 // displaces a particle by a few per cent of the spacing: most steps need none
 // or one double pass).  `anchor_seam` first: a particle that crossed the box
@@ -58,13 +81,22 @@ __device__ __forceinline__ bool lanes_ascending64(double z)
 // items in n passes.
 __device__ __forceinline__ bool sort_lanes64(double &z, int &lab, int gl)
 {
+    if (lanes_ascending64(z)) return true;
+    // partners of the even pass (0,1)(2,3).. and of the odd pass (1,2)(3,4)..
+    // (lanes 0 and 63 sit the odd pass out: their partner is themselves)
+    const int odd = gl & 1;
+    const int addr_even = (gl ^ 1) << 2;
+    const int po = odd ? (gl + 1) : (gl - 1);
+    const int addr_odd = ((po < 0 || po > 63) ? gl : po) << 2;
+    const int flip_even = odd << 31;            // the odd lane is the upper one
+    const int flip_odd = (odd ^ 1) << 31;       // the even lane is
     for (int it = 0; it < 34; ++it) {
         anchor_seam(z, lab, 64);
+        cmpxchg_pass64(z, lab, addr_even, flip_even);
+        cmpxchg_pass64(z, lab, addr_odd, flip_odd);
         if (lanes_ascending64(z)) return true;
-        resort_linear<64>(z, lab, gl, 0u, 64);
-        resort_linear<64>(z, lab, gl, 1u, 64);
     }
-    return lanes_ascending64(z);
+    return false;
 }
 
 // The once-per-walker condition beside the order: the farthest partner of the
@@ -77,6 +109,23 @@ __device__ __forceinline__ bool far_partner_ok64(const DevModel &m, double z,
     // D' = z - zp for the upper half of the lanes, z - (zp - L) for the lower
     const double d = (gl < 32) ? (z - zp) + m.L : z - zp;
     return __builtin_amdgcn_ballot_w64(d >= m.L_minus_rm) == 0ull;
+}
+
+// A table read that stays where it is written: the loops below request the
+// partner's entries ahead of their use, and the optimizer otherwise sinks a
+// plain load back to its first use (the round trip then lies in the step's
+// critical path again).
+template <typename R>
+__device__ __forceinline__ R lds_ahead(const R *p)
+{
+#if QMC_LDS_AHEAD
+    // (an explicit LDS pointer: a volatile access through a generic one is
+    // issued as a flat load)
+    typedef const volatile __attribute__((address_space(3))) R *lds_ptr;
+    return *(lds_ptr)p;
+#else
+    return *p;
+#endif
 }
 
 template <typename R>
@@ -186,90 +235,145 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     int k = 1;
 
     // ---- leading steps: every lane's partner is closer than rm ----
+    // Two steps per trip with two sets of registers for the requested tables:
+    // each set is refilled right after its step, two steps ahead of its next
+    // use, with no copies and one address update per trip.  (Left to the
+    // compiler: rolled, the loop carries two 64-bit moves and an address add per
+    // step; unrolled by its constant trip count the kernel is 25 KB.)
     QMC_SECTION("leading_short_steps");
+    // numerator / denominator of a leading (all-short) step
+#define QMC_S64_LEAD_XY(bsu, bcu, X, Y)                                       \
+    const R Y = o.c0 * (bcu) + o.s0 * (bsu);  /* f2 = |a_m| cos(k2 D' - phi) */ \
+    R X = 0;                                                                  \
+    if (EN) X = o.ks0 * (bcu) - o.kc0 * (bsu);                                \
+    if (WF) PS *= Y;
+    // the quotient's way into the sums of a step that is not the last
+#define QMC_S64_ADD_Q(q)                                                      \
+    {                                                                         \
+        Fr += (q);                                                            \
+        T -= (q);                                                             \
+        T = group_ror1<G>(T);                                                 \
+    }
     {
-        R nsu = pSU[-1], ncu = pCU[-1], nz = pZ[-1];
-        // (two steps per trip: the copies of the requested tables into the
-        // current ones disappear into the register allocation; fully unrolled
-        // -- the trip count is a constant -- the kernel is 25 KB and every exit
-        // walks a chain of moves)
-#pragma clang loop unroll_count(2)
-        for (; k < G / 2; ++k) {
-            const R bsu = nsu, bcu = ncu, bz = nz;
-            // the next step's partner (k + 1 <= G/2: inside the tables)
-            nsu = pSU[-(k + 1)]; ncu = pCU[-(k + 1)]; nz = pZ[-(k + 1)];
-            if (__builtin_amdgcn_ballot_w64(bz > o.zt) != ~0ull) break;
-            const R Y = o.c0 * bcu + o.s0 * bsu;      // f2 = |a_m| cos(k2 D' - phi)
-            if (WF) PS *= Y;
-            if (EN) {
-                const R X = o.ks0 * bcu - o.kc0 * bsu;
-                const R q = pair_div(X, Y);
-                Fr += q;
-                T -= q;
-                Qs = q_fma(q, q, Qs);
-                T = group_ror1<G>(T);
+        R asu = lds_ahead(pSU - 1), acu = lds_ahead(pCU - 1), az = lds_ahead(pZ - 1);
+        R bsu = lds_ahead(pSU - 2), bcu = lds_ahead(pCU - 2), bz = lds_ahead(pZ - 2);
+        // (k odd at the top; k + 3 <= G/2 + 1: inside the doubled tables)
+#pragma clang loop unroll(disable)
+        while (k < G / 2 - 2) {
+            if (__builtin_amdgcn_ballot_w64(az > o.zt) != ~0ull) break;
+            QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
+            asu = lds_ahead(pSU - (k + 2)); acu = lds_ahead(pCU - (k + 2));
+            az = lds_ahead(pZ - (k + 2));
+            ++k;
+            if (__builtin_amdgcn_ballot_w64(bz > o.zt) != ~0ull) {
+                if (EN) {
+                    const R q = pair_div(Xa, Ya);
+                    QMC_S64_ADD_Q(q)
+                    Qs = q_fma(q, q, Qs);
+                }
+                break;
             }
-            if (WF && sizeof(R) == 4 && (k & 7) == 0) q_fold(PS, eS);
+            QMC_S64_LEAD_XY(bsu, bcu, Xb, Yb)
+            bsu = lds_ahead(pSU - (k + 2)); bcu = lds_ahead(pCU - (k + 2));
+            bz = lds_ahead(pZ - (k + 2));
+            ++k;
+            if (EN) {
+                // (one reciprocal for both quotients -- r = 1 / (Ya Yb), qa = Xa r
+                // Yb -- measured no faster, 1 % slower in the VMC step: the
+                // reciprocal does not hold up the multiply-add pipe)
+                const R qa = pair_div(Xa, Ya), qb = pair_div(Xb, Yb);
+                QMC_S64_ADD_Q(qa)
+                QMC_S64_ADD_Q(qb)
+                Qs = q_fma(qa, qa, Qs);
+                Qs = q_fma(qb, qb, Qs);
+            }
+            if (WF && sizeof(R) == 4 && (k & 7) == 1) q_fold(PS, eS);
         }
     }
+#undef QMC_S64_LEAD_XY
     // (these pairs belong to both products and both sums)
     if (WF) { PL = PS; eL = eS; }
     if (EN) { Qall = Qs; ns = (k - 1) * G; }
 
     // ---- general steps: classified pair by pair ----
     QMC_SECTION("rotation_loop_body");
-#define QMC_S64_STEP(LAST)                                                    \
-    {                                                                         \
-        const R S = o.s * cc - o.c * cs;       /* sin(pi D' / L) > 0 */        \
-        R X = 0;                                                              \
-        if (EN) X = o.akc * cc + o.aks * cs;   /* a_long cos(pi D' / L) */     \
-        const bool mine = !(LAST) || gl < G / 2;                              \
-        const bool sh = q_abs(S) < sin_rm;     /* D' < rm */                   \
-        if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));       \
-        R Y = S;                                                              \
+    // numerator / denominator / class of a general step
+#define QMC_S64_XY(cs, cc, kk, LAST, X, Y, sh, mine)                          \
+    const R Y##_s = o.s * (cc) - o.c * (cs);   /* sin(pi D' / L) >= 0 */       \
+    R X = 0;                                                                  \
+    if (EN) X = o.akc * (cc) + o.aks * (cs);   /* a_long cos(pi D' / L) */     \
+    const bool mine = !(LAST) || gl < G / 2;                                  \
+    const bool sh = q_abs(Y##_s) < sin_rm;     /* D' < rm */                   \
+    if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));           \
+    R Y = Y##_s;                                                              \
+    if (sh) {                                                                 \
+        asm volatile("");                      /* exec-masked, not selects */  \
+        const R bsu_ = pSU[-(kk)], bcu_ = pCU[-(kk)];                         \
+        Y = o.c0 * bcu_ + o.s0 * bsu_;                                        \
+        if (EN) X = o.ks0 * bcu_ - o.kc0 * bsu_;                              \
+        if (WF && mine) PS *= Y;                                              \
+    }                                                                         \
+    if (WF && mine) PL *= Y;
+    // q^2 into the sums over all / short pairs
+#define QMC_S64_TALLY(q, sh, mine)                                            \
+    if (mine) {                                                               \
+        Qall = q_fma(q, q, Qall);                                             \
         if (sh) {                                                             \
-            asm volatile("");                  /* exec-masked, not selects */  \
-            const R bsu = pSU[-k], bcu = pCU[-k];                             \
-            Y = o.c0 * bcu + o.s0 * bsu;                                      \
-            if (EN) X = o.ks0 * bcu - o.kc0 * bsu;                            \
-            if (WF && mine) PS *= Y;                                          \
-        }                                                                     \
-        if (WF && mine) PL *= Y;                                              \
-        if (EN) {                                                             \
-            const R q = pair_div(X, Y);                                       \
-            Fr += q;                                                          \
-            if (!(LAST)) {                                                    \
-                T -= q;                                                       \
-                T = group_ror1<G>(T);                                         \
-            }                                                                 \
-            if (mine) {                                                       \
-                Qall = q_fma(q, q, Qall);                                     \
-                if (sh) {                                                     \
-                    asm volatile("");                                         \
-                    Qs = q_fma(q, q, Qs);                                     \
-                }                                                             \
-            }                                                                 \
+            asm volatile("");                                                 \
+            Qs = q_fma(q, q, Qs);                                             \
         }                                                                     \
     }
     {
-        R bs = pS[-k], bc = pC[-k];
-#pragma clang loop unroll_count(2)
-        for (; k < G / 2; ++k) {
-            const R cs = bs, cc = bc;
-            bs = pS[-(k + 1)]; bc = pC[-(k + 1)];
-            QMC_S64_STEP(false)
-            if (WF && sizeof(R) == 4 && (k & 7) == 0) {
+        R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k);   // step k
+        // step k + 1 (<= G/2)
+        R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1));
+#pragma clang loop unroll(disable)
+        while (k < G / 2 - 1) {
+            QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
+            as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
+            QMC_S64_XY(bs_, bc_, k + 1, false, Xb, Yb, shb, mineb)
+            // (k + 3 <= G/2 + 1: inside the doubled tables)
+            bs_ = lds_ahead(pS - (k + 3)); bc_ = lds_ahead(pC - (k + 3));
+            k += 2;
+            if (EN) {
+                // (one reciprocal for both quotients -- r = 1 / (Ya Yb), qa = Xa r
+                // Yb -- measured no faster, 1 % slower in the VMC step: the
+                // reciprocal does not hold up the multiply-add pipe)
+                const R qa = pair_div(Xa, Ya), qb = pair_div(Xb, Yb);
+                QMC_S64_ADD_Q(qa)
+                QMC_S64_ADD_Q(qb)
+                QMC_S64_TALLY(qa, sha, minea)
+                QMC_S64_TALLY(qb, shb, mineb)
+            }
+            if (WF && sizeof(R) == 4) {
                 q_fold(PS, eS);
                 q_fold(PL, eL);
             }
         }
+        if (k < G / 2) {
+            // an odd number of steps was left: step G/2 - 1 is in the first set
+            QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
+            if (EN) {
+                const R q = pair_div(Xa, Ya);
+                QMC_S64_ADD_Q(q)
+                QMC_S64_TALLY(q, sha, minea)
+            }
+            ++k;
+            as_ = bs_; ac_ = bc_;
+        }
         // the final half step visits every pair from both sides: each side
         // updates its own particle, the lower half of the lanes tallies
         QMC_SECTION("rotation_last_step");
-        const R cs = bs, cc = bc;
-        QMC_S64_STEP(true)
+        QMC_S64_XY(as_, ac_, k, true, Xl, Yl, shl, minel)
+        if (EN) {
+            const R q = pair_div(Xl, Yl);
+            Fr += q;
+            QMC_S64_TALLY(q, shl, minel)
+        }
     }
-#undef QMC_S64_STEP
+#undef QMC_S64_XY
+#undef QMC_S64_TALLY
+#undef QMC_S64_ADD_Q
     if (EN) Fr += __shfl_xor(T, G / 2, 64);
 
     QMC_SECTION("energy+logwf");
