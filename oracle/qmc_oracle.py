@@ -78,8 +78,10 @@ def build(force=False):
 
 _lib = None
 _active_path = _LIB_PATH
-NATIVE_FLAGS = ('-O3 -march=native -fPIC -fopenmp -ffp-contract=off '
-                '-fno-builtin -std=gnu11')
+_native_dir = None
+# (the TIMED build: libm builtins allowed -- numba's LLVM inlines fabs /
+# copysign / sqrt too; the bit-exact checker of the Makefile keeps -fno-builtin)
+NATIVE_FLAGS = '-O3 -march=native -fPIC -fopenmp -ffp-contract=off -std=gnu11'
 
 
 def build_native():
@@ -90,12 +92,16 @@ def build_native():
     library `lib()` loads from now on.  Still no -ffast-math and no FMA
     contraction: the reference default is jit_fastmath=False.
     -> the flag string of the build in use."""
-    global _lib, _active_path
+    global _lib, _active_path, _native_dir
     import tempfile
-    out_dir = os.path.join(tempfile.gettempdir(),
-                           f'qmc_oracle_native_{os.getuid()}')
-    os.makedirs(out_dir, exist_ok=True)
-    out = os.path.join(out_dir, 'libqmc_oracle_native.so')
+    # a private directory (mode 0700, fresh name): nobody else can put a
+    # library where this process is about to load one from
+    if _native_dir is None:
+        import atexit
+        import shutil
+        _native_dir = tempfile.mkdtemp(prefix='qmc_oracle_native_')
+        atexit.register(shutil.rmtree, _native_dir, ignore_errors=True)
+    out = os.path.join(_native_dir, 'libqmc_oracle_native.so')
     cc = os.environ.get('CC', 'gcc')
     cmd = [cc] + NATIVE_FLAGS.split() + ['-shared', '-o', out,
                                          os.path.join(_HERE, 'qmc_oracle.c'),

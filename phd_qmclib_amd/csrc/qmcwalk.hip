@@ -1649,8 +1649,13 @@ static bool dmc_fused_branching(const qmc_dmc *d)
 // Enqueue the rank-local part of one time step.  `prev_fin`: the bookkeeping of
 // the step before, to ride at the head of the fused branching kernel (only
 // where dmc_fused_branching(d)).
+// `prev_fin_done` (if given) is set once the fused branching kernel -- which
+// applies the previous step's deferred bookkeeping `prev_fin` at its head --
+// has been enqueued: a caller that sees an error must launch that bookkeeping
+// itself only while the flag is still false.
 static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev,
-                             const FinishArgs *prev_fin = nullptr)
+                             const FinishArgs *prev_fin = nullptr,
+                             bool *prev_fin_done = nullptr)
 {
     qmc_engine *e = d->eng;
     const int par = d->cur, chi = 1 - d->cur;
@@ -1674,6 +1679,7 @@ static int dmc_enqueue_local(qmc_dmc *d, double *partial_dev,
         hipLaunchKernelGGL(branch_fused_kernel, dim3(1), dim3(BLOCK), 0,
                            e->stream, b, partial_dev,
                            prev_fin ? *prev_fin : none, prev_fin ? 1 : 0);
+        if (prev_fin_done) *prev_fin_done = true;
     } else {
         if (prev_fin) return fail("qmc_dmc: internal: deferred bookkeeping "
                                   "needs the fused branching kernel");
@@ -1762,13 +1768,18 @@ extern "C" int qmc_dmc_run_block(qmc_dmc *d, int64_t nsteps, double *energy,
         FinishArgs pend{};
         bool have = false;
         for (long long t = 0; t < nsteps; ++t) {
-            int rc = dmc_enqueue_local(d, nullptr, have ? &pend : nullptr);
+            bool pend_done = false;
+            int rc = dmc_enqueue_local(d, nullptr, have ? &pend : nullptr,
+                                       &pend_done);
             if (rc) {
-                // (nothing was launched for this step: the step before still
-                // needs its bookkeeping)
-                if (have)
+                // the step before still needs its bookkeeping -- unless this
+                // step's branching kernel, which carries it, was enqueued
+                // before the failure (then it has been applied, once)
+                if (have && !pend_done) {
                     hipLaunchKernelGGL(dmc_finish_kernel, dim3(1), dim3(BLOCK),
                                        0, d->eng->stream, pend);
+                    (void)hipGetLastError();   // the first error is reported
+                }
                 return rc;
             }
             pend = dmc_finish_args(d, nullptr, t);
@@ -1817,17 +1828,32 @@ extern "C" int qmc_dmc_set_estimators(qmc_dmc *d, const qmc_dmc_est_params *p)
     d->est_last_act = 1;
     d->have_est = false;
     d->est = *p;
-    d->have_est = p->num_modes > 0 || p->num_bins > 0;
+    const bool want = p->num_modes > 0 || p->num_bins > 0;
     const size_t W = (size_t)d->maxw;
+    // estimators are on only once every buffer exists: a failed allocation
+    // leaves the population without estimators (and without half of their
+    // buffers), not with `have_est` set over null pointers
+    bool failed = false;
     if (p->num_modes > 0)
-        for (int k = 0; k < 2; ++k)
-            if (dev_alloc(&d->ssf_aux[k], W * (size_t)p->num_modes * 3)) return 1;
+        for (int k = 0; k < 2 && !failed; ++k)
+            failed = dev_alloc(&d->ssf_aux[k], W * (size_t)p->num_modes * 3) != 0;
     if (p->num_bins > 0)
-        for (int k = 0; k < 2; ++k)
-            if (dev_alloc(&d->dens_aux[k], W * (size_t)p->num_bins)) return 1;
+        for (int k = 0; k < 2 && !failed; ++k)
+            failed = dev_alloc(&d->dens_aux[k], W * (size_t)p->num_bins) != 0;
     size_t kc = (size_t)(p->num_modes * 3 > p->num_bins ? p->num_modes * 3
                                                         : p->num_bins);
-    if (d->have_est && dev_alloc(&d->est_partial, EST_BLOCKS * kc)) return 1;
+    if (want && !failed)
+        failed = dev_alloc(&d->est_partial, EST_BLOCKS * kc) != 0;
+    if (failed) {
+        for (int k = 0; k < 2; ++k) {
+            if (d->ssf_aux[k]) { hipFree(d->ssf_aux[k]); d->ssf_aux[k] = nullptr; }
+            if (d->dens_aux[k]) { hipFree(d->dens_aux[k]); d->dens_aux[k] = nullptr; }
+        }
+        if (d->est_partial) { hipFree(d->est_partial); d->est_partial = nullptr; }
+        d->est.num_modes = d->est.num_bins = 0;
+        return 1;            // (dev_alloc has set the message)
+    }
+    d->have_est = want;
     return 0;
 }
 

@@ -34,6 +34,7 @@ The reference has no distributed path at all; its global cap
 `max_num_walkers` becomes a per-rank cap max_num_walkers / world here.
 """
 import ctypes as C
+import time
 import typing as t
 
 import numpy as np
@@ -93,6 +94,13 @@ def _wrap_f64(ptr: int, count: int, device: torch.device) -> torch.Tensor:
     return torch.from_numpy(arr)
 
 
+def _wrap_i64(ptr: int, count: int, device: torch.device) -> torch.Tensor:
+    """View `count` 64-bit integers at device address `ptr`."""
+    src = _RawDeviceArray(ptr, count)
+    src.__cuda_array_interface__['typestr'] = '<i8'
+    return torch.as_tensor(src, device=device)
+
+
 class DistributedVmc:
     """Chains sharded over ranks; per-block global sums by all-reduce."""
 
@@ -105,13 +113,31 @@ class DistributedVmc:
         self.device = device
 
     def run_block(self, num_steps: int) -> t.Dict[str, float]:
-        """-> global block statistics (identical on every rank)."""
-        out = self.sampling.ensemble.run_block(int(num_steps))
-        loc = torch.tensor([out['sum_energy'].sum(),
-                            out['sum_energy2'].sum(),
-                            float(out['num_accepted'].sum()),
-                            float(self.chains_per_rank * num_steps)],
-                           dtype=torch.float64, device=self.device)
+        """-> global block statistics (identical on every rank).  The
+        per-chain sums of a GPU ensemble are reduced where they are (24 bytes
+        per chain stay in HBM; four doubles cross to the other ranks and to the
+        host); the CPU stand-in of the tests hands back host arrays."""
+        ens = self.sampling.ensemble
+        dev = None if self.device is None else torch.device(self.device)
+        n_samples = float(self.chains_per_rank * num_steps)
+        if dev is not None and dev.type == 'cuda' and \
+                hasattr(ens, 'block_sums_dev'):
+            ens.run_block(int(num_steps), sums=False)
+            # the engine may launch on a stream of its own: its block is
+            # complete before torch reads the sums
+            ens.engine.sync()
+            W = self.chains_per_rank
+            p_e, p_e2, p_acc = ens.block_sums_dev()
+            loc = torch.stack([
+                _wrap_f64(p_e, W, dev).sum(), _wrap_f64(p_e2, W, dev).sum(),
+                _wrap_i64(p_acc, W, dev).sum().to(torch.float64),
+                torch.tensor(n_samples, dtype=torch.float64, device=dev)])
+        else:
+            out = ens.run_block(int(num_steps))
+            loc = torch.tensor([out['sum_energy'].sum(),
+                                out['sum_energy2'].sum(),
+                                float(out['num_accepted'].sum()), n_samples],
+                               dtype=torch.float64, device=self.device)
         if self.world > 1:
             dist.all_reduce(loc)
         se, se2, na, n = loc.tolist()
@@ -149,6 +175,7 @@ class DistributedDmc:
         self.walkers_moved = 0
         self.rebalances = 0
         self._inflight = []      # transfer buffers of the last rebalance
+        self._phase = None       # per-phase timings (enable_phase_timing)
 
     def _check_stream(self):
         """The collectives are ordered with the engine's kernels only when
@@ -172,13 +199,65 @@ class DistributedDmc:
     def _ptr(self, tensor):
         return tensor.data_ptr()
 
+    # ---- per-phase timings (bench.py `extra.phases`) ----------------------
+    def enable_phase_timing(self, max_steps: int = 4096):
+        """From now on record, per time step, the duration of the all-reduce
+        on the stream (an event pair around it; wall clock with gloo) and the
+        host time spent enqueueing the step, and per rebalance its wall time.
+        Costs two event records per step; read with `phase_report`."""
+        ph = dict(steps=0, host_enqueue_s=0.0, allreduce_wall_s=0.0,
+                  rebalance_s=0.0, rebalance_calls=0, events=[], free=[])
+        if self.device.type == 'cuda' and self._collect:
+            ph['free'] = [torch.cuda.Event(enable_timing=True)
+                          for _ in range(2 * int(max_steps))]
+        self._phase = ph
+
+    def phase_report(self) -> t.Optional[t.Dict[str, float]]:
+        """Synchronises.  -> dict(steps, allreduce_us_per_step,
+        allreduce_us_max, host_enqueue_us_per_step, rebalance_ms_total,
+        rebalance_calls) since `enable_phase_timing`, or None."""
+        ph = self._phase
+        if ph is None:
+            return None
+        steps = max(ph['steps'], 1)
+        ar = [0.0]
+        if ph['events']:
+            torch.cuda.synchronize(self.device)
+            ar = [a.elapsed_time(b) * 1e3 for a, b in ph['events']]   # us
+            mean_ar = sum(ar) / len(ar)
+        else:
+            mean_ar = ph['allreduce_wall_s'] * 1e6 / steps
+        return dict(steps=ph['steps'], allreduce_us_per_step=mean_ar,
+                    allreduce_us_max=max(ar) if ph['events'] else None,
+                    allreduce_timed_with='hip events on the stream'
+                    if ph['events'] else 'host wall clock',
+                    host_enqueue_us_per_step=ph['host_enqueue_s'] * 1e6 / steps,
+                    rebalance_ms_total=ph['rebalance_s'] * 1e3,
+                    rebalance_calls=ph['rebalance_calls'])
+
     def step(self):
         """One global time step, fully enqueued (no host synchronisation)."""
+        ph = self._phase
+        t0 = time.perf_counter() if ph is not None else 0.0
         self.ens.step_local(self._ptr(self.sums))
         if self._collect:
-            dist.all_reduce(self.sums)          # 16 bytes, in place
+            if ph is not None and len(ph['free']) >= 2:
+                e0, e1 = ph['free'].pop(), ph['free'].pop()
+                e0.record()
+                dist.all_reduce(self.sums)      # 16 bytes, in place
+                e1.record()
+                ph['events'].append((e0, e1))
+            elif ph is not None:
+                t1 = time.perf_counter()
+                dist.all_reduce(self.sums)
+                ph['allreduce_wall_s'] += time.perf_counter() - t1
+            else:
+                dist.all_reduce(self.sums)      # 16 bytes, in place
         self.ens.step_finish(self._ptr(self.sums))
         self.steps_done += 1
+        if ph is not None:
+            ph['steps'] += 1
+            ph['host_enqueue_s'] += time.perf_counter() - t0
 
     def run_block(self, num_steps: int, estimators: bool = False):
         """`num_steps` time steps with periodic population rebalance;
@@ -238,6 +317,7 @@ class DistributedDmc:
         """Level the local populations; -> number of walkers this rank sent
         or received.  One host synchronisation (the walker counts); packing,
         transfers, unpacking and the new population size are stream-ordered."""
+        t_start = time.perf_counter()
         counts = self.global_counts()
         mean = sum(counts) / len(counts)
         if not force and mean > 0 and \
@@ -280,4 +360,8 @@ class DistributedDmc:
         self._inflight = keep
         self.walkers_moved += moved
         self.rebalances += 1 if moved else 0
+        self.last_counts = counts          # before the transfers
+        if self._phase is not None:
+            self._phase['rebalance_s'] += time.perf_counter() - t_start
+            self._phase['rebalance_calls'] += 1
         return moved

@@ -185,6 +185,18 @@ class Sampling:
 
     def _new_ensemble(self, target=None, slot0=0, device=None, stream=None,
                       external_reduce=False):
+        if self.fast_math_in_effect:
+            # in the reference `fastmath` relaxes IEEE rules but still computes
+            # in double; here it changes the precision CLASS of the pair loop:
+            # say so every time
+            import warnings
+            warnings.warn(
+                'jit_fastmath=True with jit_parallel=True runs the pair loop '
+                'in float (fp32) on the device: local energy ~1e-7 relative, '
+                'drift of a pair closer than ~1e-6 L loses its leading digits '
+                '(DESIGN.md section 4, "Reduced precision"); the DMC result '
+                'with this option is not pinned against the reference',
+                RuntimeWarning, stacklevel=3)
         eng = ModelEngine(self.model_spec.cfc_spec, device=device,
                           stream=stream, fast_math=self.fast_math_in_effect)
         ens = DmcEnsemble(eng, self.time_step, self.max_num_walkers,

@@ -18,6 +18,8 @@ from tests._dist_worker import OracleShard
 class Backend:
     dist_backend = 'gloo'
     has_vmc = False
+    name = 'cpu-standin (oracle + gloo; tests only)'
+    data = 'cpu-standin'
 
     def __init__(self, local_rank):
         # (a rank that dies before it joins the process group: launcher test)
@@ -29,12 +31,12 @@ class Backend:
     def sync(self):
         pass
 
-    def sharded_population(self, n, per_rank, cap, global_target, rank, world,
+    def sharded_population(self, n, start, cap, global_target, rank, world,
                            equil, rebalance_every):
         model = orc.model_from_cfc(box_spec(n).cfc_spec)
         rng = np.random.RandomState(100 + rank)
-        pos = n * rng.random_sample((per_rank, n))
+        pos = n * rng.random_sample((start, n))
         shard = OracleShard(orc, model, pos, 6.25e-4, cap, global_target, 0.5,
-                            seed=1, slot0=rank * cap)
+                            seed=1, slot0=rank << 26)
         dd = DistributedDmc(shard, n, 'cpu', rebalance_every=rebalance_every)
-        return shard, dd, None, per_rank
+        return shard, dd, None, start

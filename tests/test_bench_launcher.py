@@ -28,7 +28,8 @@ def run_bench(args, env_extra, timeout=240):
 def test_bench_spawns_two_ranks(oracle):
     r = run_bench(['--gpus', '2', '--steps', '6', '--warmup', '2',
                    '--c4-bosons', '8', '--c4-walkers', '48',
-                   '--rebalance-every', '2', '--no-checks'],
+                   '--rebalance-every', '2', '--start-skew', '0.25',
+                   '--no-checks'],
                   {'QMC_BENCH_BACKEND': 'tests._bench_standin'})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -43,6 +44,26 @@ def test_bench_spawns_two_ranks(oracle):
     # W_t of every step is the sum over BOTH ranks: about the global target
     assert 30 < out['extra']['mean_walkers'] < 70
     assert 'cpu_baseline' not in out                # rank 0 at N = 1 only
+    # the line says which engine produced it
+    assert out['backend'].startswith('cpu-standin')
+    assert out['data'] == 'cpu-standin'
+    # the ranks started 30 / 18 and the forced rebalances really moved walkers
+    # (warm-up: 6 sent + 6 received), conserving the population
+    ex = out['extra']
+    wu = ex['rebalance_checks']['warmup']
+    assert sum(wu['counts_before']) == sum(wu['counts_after'])
+    assert max(wu['counts_after']) - min(wu['counts_after']) <= 1
+    assert max(wu['counts_before']) - min(wu['counts_before']) >= 6
+    assert ex['walkers_moved_warmup_all_ranks'] >= 12
+    tm = ex['rebalance_checks']['timed']
+    assert sum(tm['counts_before']) == sum(tm['counts_after'])
+    assert ex['walkers_moved_all_ranks'] > 0
+    assert ex['ref_energy_identical_on_all_ranks'] is True
+    ph = ex['phases']
+    assert ph['steps'] == 6 and ph['rebalance_calls'] >= 1
+    assert ph['allreduce_us_per_step_max_over_ranks'] > 0
+    assert ph['host_enqueue_us_per_step_max_over_ranks'] > 0
+    assert ph['rebalance_ms_total_max_over_ranks'] > 0
 
 
 def test_bench_refuses_world_size_mismatch():

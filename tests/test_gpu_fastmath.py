@@ -147,3 +147,89 @@ def test_fast_math_energy_shift_in_sigma_n64():
     # both are the physical trial-state energy of the box
     for s in stats.values():
         assert 15.5 < s['mean'] < 15.9
+
+
+def test_fast_math_error_vs_pair_separation():
+    """the float pair loop between the pinned regimes.  One pair of
+    an otherwise regular N = 64 configuration is brought to separations from
+    1e-2 down to 1e-9 (the goldens hold > 1e-3 and 1e-9 only); energy, log|psi|
+    and drift of both precisions against the double path.  What limits the
+    float loop there is the SIGN of sin(pi d / L) (the direction of the pair's
+    drift), lost once pi d / L falls below the float rounding of the products
+    (~6e-8 / (pi / L) ~ 1e-6 L): the pair is a short-range one, its factor
+    cos(k2 r - phi) and |f2'/f2| are smooth at r -> 0, so energy and log|psi|
+    stay at float accuracy at every separation."""
+    from phd_qmclib_amd.engine import ModelEngine
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    n = 64
+    spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                interaction_strength=2, boson_number=n, supercell_size=n,
+                tbf_contact_cutoff=0.25 * n)
+    seps = [1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9]
+    base = np.arange(n) + 0.3 + 0.05 * np.random.RandomState(5).randn(n)
+    pos = np.repeat(base[None, :], len(seps), axis=0)
+    for k, d in enumerate(seps):
+        pos[k, 11] = pos[k, 10] + d
+    f32 = ModelEngine(spec.cfc_spec, fast_math=True)
+    f64 = ModelEngine(spec.cfc_spec)
+    a, b = f32.evaluate(pos), f64.evaluate(pos)
+    rows = {}
+    for k, d in enumerate(seps):
+        dscale = np.abs(b.drift[k]).max()
+        rows[f'{d:g}'] = dict(
+            energy_rel=float(abs(a.energy[k] - b.energy[k]) /
+                             max(1.0, abs(b.energy[k]))),
+            wf_rel=float(abs(a.wf_abs_log[k] - b.wf_abs_log[k]) /
+                         max(1.0, abs(b.wf_abs_log[k]))),
+            drift_rel_of_max=float(np.abs(a.drift[k] - b.drift[k]).max() /
+                                   dscale))
+    _report({'pair_separation_scan_n64': rows})
+    for d, r in rows.items():
+        assert r['energy_rel'] <= TOL_ENERGY, rows
+        assert r['wf_rel'] <= TOL_WF, rows
+        # drift: float accuracy while the sign of the separation survives
+        # (measured: 4.5e-7 of the largest component for every separation
+        # down to 1e-7), bounded by twice the pair's own share (|f2'/f2| at
+        # contact, ~8 % of the largest component) below that
+        if float(d) >= 1e-7:
+            assert r['drift_rel_of_max'] <= 5e-6, rows
+        else:
+            assert r['drift_rel_of_max'] <= 0.5, rows
+    f32.close()
+    f64.close()
+
+
+def test_fast_math_dmc_energy_shift_in_sigma_n64():
+    """the DMC counterpart of the VMC check above.  Eight
+    independent populations (512 walkers, 150 + 250 time steps) per precision
+    on the same seeds; the mean shift of the mixed energy per particle in
+    units of the run-to-run Monte-Carlo error of the double path (2 sigma)."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    from phd_qmclib_amd.mrbp_qmc import Spec
+    n, target, maxw, K = 64, 512, 640, 8
+    spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1,
+                interaction_strength=2, boson_number=n, supercell_size=n,
+                tbf_contact_cutoff=0.25 * n)
+    start = n * np.random.RandomState(4).random_sample((target, n))
+    res = {}
+    for fast in (False, True):
+        eng = ModelEngine(spec.cfc_spec, fast_math=fast)
+        vals = []
+        for k in range(K):
+            d = DmcEnsemble(eng, 1e-3, maxw, target, 0.5, rng_seed=700 + k)
+            d.set_state(start)
+            d.run_block(150, read=False)
+            s = d.run_block(250)
+            vals.append(s.energy.sum() / s.weight.sum() / n)
+            d.close()
+        res[fast] = np.array(vals)
+        eng.close()
+    err = res[False].std(ddof=1) / np.sqrt(K)
+    shift = float((res[True].mean() - res[False].mean()) / err)
+    _report({'dmc_n64_shift': dict(
+        f64_mean=float(res[False].mean()), f32_mean=float(res[True].mean()),
+        f64_err=float(err), shift_in_sigma=shift,
+        note=f'{K} populations of {target} walkers, 150 + 250 steps, dt 1e-3, '
+             f'same seeds')})
+    assert abs(shift) < 2.0, res
+    assert 14.5 < res[True].mean() < 16.5

@@ -503,18 +503,22 @@ def test_vmc_n64_statistics_vs_oracle(oracle):
 def test_dmc_n64_statistics_vs_oracle(oracle):
     """Same gate for DMC at N = 64: independent ensembles of 128 walkers (same
     population, hence the same population-control bias) on the device (96
-    seeds) and in the oracle (24 seeds); time-averaged E/N and mean population
-    within the 2-sigma-equivalent of Welch's t (the run-to-run spread is
-    estimated from the runs themselves, so the critical value is Student's:
-    same 4.6 % nominal false-alarm probability per quantity).
+    seeds) and in the oracle (24 seeds), POOLED with the 16 + 8 seeds of the
+    first version of this test (see below): 112 against 32 runs; time-averaged
+    E/N and mean population within the 2-sigma-equivalent of Welch's t (the
+    run-to-run spread is estimated from the runs themselves, so the critical
+    value is Student's: same 4.6 % nominal false-alarm probability per
+    quantity).
 
     Before that, the stronger statement the counter-based generator allows:
     on EQUAL seeds the device follows the oracle's trajectory, so both
     quantities agree to rounding run by run -- the two sides are the same
     process in law, and the independent-seed gate measures nothing but
-    Monte-Carlo noise.  (For the record: a first choice of 16 + 8 seeds gave
-    t = 2.8 for the mean population, a 1 % event; the same comparison with 96
-    + 24 other seeds gives |t| < 1, and the equal-seed runs are identical.)"""
+    Monte-Carlo noise.  (For the record: the first choice of 16 + 8 seeds
+    -- device 100..115, oracle 200..207 -- gave t = 2.8 for the mean
+    population on its own, a 1 % event.  Round 2 replaced those seeds; a
+    failing sample is not discarded, so they are pooled with the 96 + 24
+    here and the t values of the pooled sample and of both parts are printed.)"""
     from scipy import stats
     from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
     spec = box(64)
@@ -542,22 +546,34 @@ def test_dmc_n64_statistics_vs_oracle(oracle):
             e += y.energy; w += y.weight; nw += y.num_walkers
         return e / w / 64, nw / ns
 
-    orc = np.array([orc_run(3000 + k) for k in range(24)])
+    orc = np.array([orc_run(3000 + k) for k in range(24)] +
+                   [orc_run(200 + k) for k in range(8)])
     # equal seeds: the same trajectories (500 steps of branching decisions)
     same = np.array([dev_run(3000 + k) for k in range(3)])
     assert np.array_equal(same[:, 1], orc[:3, 1])
     assert np.allclose(same[:, 0], orc[:3, 0], rtol=1e-9, atol=0)
-    dev = np.array([dev_run(1000 + k) for k in range(96)])
-    report = {}
-    for col, name in ((0, 'E/N'), (1, '<nw>')):
-        a, b = dev[:, col], orc[:, col]
+    dev = np.array([dev_run(1000 + k) for k in range(96)] +
+                   [dev_run(100 + k) for k in range(16)])
+
+    def welch(a, b):
         va, vb = a.var(ddof=1) / len(a), b.var(ddof=1) / len(b)
         t = (a.mean() - b.mean()) / np.sqrt(va + vb)
         dof = (va + vb) ** 2 / (va ** 2 / (len(a) - 1) + vb ** 2 / (len(b) - 1))
         crit = stats.t.ppf(1 - 0.0455 / 2, dof)      # "2 sigma" for Student's t
-        report[name] = (float(t), float(crit), float(a.mean()), float(b.mean()))
-    print('N=64 DMC t values (t, 2-sigma critical value, dev, oracle):', report)
-    for name, (t, crit, _, _) in report.items():
+        return float(t), float(crit)
+
+    report = {}
+    for col, name in ((0, 'E/N'), (1, '<nw>')):
+        a, b = dev[:, col], orc[:, col]
+        t, crit = welch(a, b)
+        report[name] = dict(
+            pooled=(t, crit, float(a.mean()), float(b.mean())),
+            seeds_96_24=welch(a[:96], b[:24]),
+            seeds_16_8_round1=welch(a[96:], b[24:]))
+    print('N=64 DMC t values (t, 2-sigma critical value[, dev, oracle]):',
+          report)
+    for name, r in report.items():
+        t, crit = r['pooled'][:2]
         assert abs(t) < crit, (name, report)
     assert 14.5 < dev[:, 0].mean() < 16.5
     eng.close()
