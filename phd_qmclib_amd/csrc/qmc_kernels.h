@@ -6,6 +6,11 @@
 
 #include "qmc_device.h"
 #include "qmc_sorted64.h"
+#include "qmc_sorted128.h"
+
+#ifndef QMC_SORTED128
+#define QMC_SORTED128 1
+#endif
 
 static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 
@@ -23,6 +28,16 @@ static constexpr int BLOCK = 256;          // 4 wavefronts per workgroup
 template <int G>
 struct WalkBlock {
     static constexpr int N = (G == 64) ? QMC_BLOCK64 : BLOCK;
+};
+
+// LDS doubles per lane group of the stepping kernels (vmc_step, dmc_evolve):
+// the sorted-row path of the exact N = 128 shape keeps doubled tables and the
+// positions, 5 rows of 256 entries (qmc_sorted128.h)
+template <int G, int P, bool PAD, bool ZC>
+struct StepLds {
+    static constexpr int DOUBLES =
+        (QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC)
+            ? 5 * 2 * 128 : GroupLds<G, P, ZC>::DOUBLES;
 };
 
 // a wave-uniform 64-bit value as the compiler can see it (scalar registers)
@@ -191,7 +206,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
     const long long w = (long long)blockIdx.x * GPB + grp;
     const bool active = w < a.W;
     const long long wr = active ? w : 0;
@@ -253,10 +268,14 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // well enough: a particle moves a few per cent of the spacing per step)
     // exactly ascending lanes: the fast pair sum of qmc_sorted64.h
     constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !PAD && !ZC;
+    constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC;
     bool fast = false;
     if constexpr (S64) {
         fast = !m.is_ideal && sort_lanes64(zn[0], labn[0], gl) &&
                far_partner_ok64(m, zn[0], gl);
+    } else if constexpr (S128) {
+        fast = !m.is_ideal && sort_rows128(zn, labn, gl) &&
+               far_partner_ok128(m, zn, gl);
     } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         // ascending order, wrap point anchored at the lane seam (qmc_device.h)
         // (one particle per lane: lanes 0 .. n-1 hold them)
@@ -281,6 +300,10 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
         if constexpr (S64)
             eval_sorted64<R, true, !TWO_PASS, false>(m, zn[0], gl, lds, F[0],
                                                      e_new, wf_new);
+    } else if (S128 && fast) {
+        if constexpr (S128)
+            eval_sorted128<R, true, !TWO_PASS, false>(m, zn, gl, lds, F, e_new,
+                                                      wf_new);
     } else if constexpr (TWO_PASS)
         eval_walker<G, P, PAD, true, false, ZC, R, false, false>(
             m, zn, gl, lds, F, ei, e_new, wf_new);
@@ -332,6 +355,10 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
                 if constexpr (S64)
                     eval_sorted64<R, false, true, true>(m, zn[0], gl, lds, F[0],
                                                         e_new, wf_unused);
+            } else if (S128 && fast) {
+                if constexpr (S128)
+                    eval_sorted128<R, false, true, true>(m, zn, gl, lds, F,
+                                                         e_new, wf_unused);
             } else
                 eval_walker<G, P, PAD, false, false, ZC, R, true, true>(
                     m, zn, gl, lds, F, ei, e_new, wf_unused);
@@ -422,7 +449,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
+    double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
     const long long s = (long long)blockIdx.x * GPB + grp;
     const long long nw = a.ctl->nw;
     // whole block beyond the population: nothing to do
@@ -483,10 +510,14 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     }
     QMC_SECTION("resort");
     constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !PAD && !ZC;
+    constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC;
     bool fast = false;
     if constexpr (S64) {
         fast = !m.is_ideal && sort_lanes64(z[0], lab[0], gl) &&
                far_partner_ok64(m, z[0], gl);
+    } else if constexpr (S128) {
+        fast = !m.is_ideal && sort_rows128(z, lab, gl) &&
+               far_partner_ok128(m, z, gl);
     } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         anchor_seam(z[0], lab[0], n);
         if ((step % QMC_RESORT_EVERY) == 0)
@@ -512,6 +543,9 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         if constexpr (S64)
             eval_sorted64<R, false, true, false>(m, z[0], gl, lds, F[0], e_next,
                                                  wf);
+    } else if (S128 && fast) {
+        if constexpr (S128)
+            eval_sorted128<R, false, true, false>(m, z, gl, lds, F, e_next, wf);
     } else
         eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei,
                                                     e_next, wf);

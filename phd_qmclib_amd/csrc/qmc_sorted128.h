@@ -1,0 +1,336 @@
+// qmc_sorted128.h -- the pair sum on exactly ascending rows (qmc_sorted64.h) for
+// the shape of BASELINE configs[3]: one walker per wavefront, TWO particles per
+// lane, N = 128 (the multi-GPU headline workload).
+//
+// A lane holds the consecutive slots 2 gl, 2 gl + 1 of the sorted row.  At
+// rotation step k it meets the two particles of lane gl - k: four pairs, at
+// slot distances 2k - 1, 2k, 2k, 2k + 1.  The LDS tables are doubled as for one
+// particle per lane (upper copy = the particle, lower copy = the particle one
+// period below), so every pair is seen unwrapped and ordered, D' >= 0, and D'
+// grows with the slot distance.  Hence:
+//   * leading steps: ONE compare per step -- the farthest of the four pairs
+//     (own slot 1 against the partner's slot 0) is short for every lane -- and
+//     four one-case short-range pairs with no classification at all (the old
+//     two-particle path had no such phase: every pair was classified and went
+//     through the two-case branches);
+//   * general steps: a pair is short iff |sin(pi D' / L)| < sin(pi rm / L), in
+//     the single case; no generic branch;
+//   * once per walker: the row is ascending and the farthest partner of the
+//     rotation (slot distance 65) is closer than L - rm.
+// Two steps per trip with two register sets for the requested partner tables.
+#pragma once
+
+#include "qmc_sorted64.h"
+
+// ---- exact order of a row of 128 slots, two per lane ------------------------
+// ascending: z0 <= z1 inside every lane and z1 <= the next lane's z0
+__device__ __forceinline__ bool rows_ascending128(const double (&z)[2])
+{
+    // lane i takes the next lane's first slot (the last lane keeps its own)
+    const int lo = __double2loint(z[0]), hi = __double2hiint(z[0]);
+    const double up = __hiloint2double(
+        __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false),
+        __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));
+    const bool last = (threadIdx.x & 63) == 63;
+    const bool bad = (z[1] < z[0]) | (!last & (up < z[1]));
+    return __builtin_amdgcn_ballot_w64(bad) == 0ull;
+}
+
+__device__ __forceinline__ bool sort_rows128(double (&z)[2], int (&lab)[2], int gl)
+{
+    if (rows_ascending128(z)) return true;
+    const int lane = threadIdx.x & 63;
+    const int a_up = (lane == 63 ? lane : lane + 1) << 2;
+    const int a_dn = (lane == 0 ? lane : lane - 1) << 2;
+    for (int it = 0; it < 66; ++it) {
+        anchor_seam_rows<2>(z, lab, 128);
+        // even phase: the two slots of a lane
+        {
+            const bool sw = z[1] < z[0];
+            const double t = z[0]; const int u = lab[0];
+            z[0] = sw ? z[1] : z[0]; lab[0] = sw ? lab[1] : lab[0];
+            z[1] = sw ? t : z[1];    lab[1] = sw ? u : lab[1];
+        }
+        // odd phase: (slot 1 of a lane, slot 0 of the next); both lanes of a
+        // pair see the same two values
+        {
+            const double up = __hiloint2double(
+                __builtin_amdgcn_ds_bpermute(a_up, __double2hiint(z[0])),
+                __builtin_amdgcn_ds_bpermute(a_up, __double2loint(z[0])));
+            const int lup = __builtin_amdgcn_ds_bpermute(a_up, lab[0]);
+            const double dn = __hiloint2double(
+                __builtin_amdgcn_ds_bpermute(a_dn, __double2hiint(z[1])),
+                __builtin_amdgcn_ds_bpermute(a_dn, __double2loint(z[1])));
+            const int ldn = __builtin_amdgcn_ds_bpermute(a_dn, lab[1]);
+            const bool t_up = lane < 63 && up < z[1];
+            const bool t_dn = lane > 0 && dn > z[0];
+            z[1] = t_up ? up : z[1]; lab[1] = t_up ? lup : lab[1];
+            z[0] = t_dn ? dn : z[0]; lab[0] = t_dn ? ldn : lab[0];
+        }
+        if (rows_ascending128(z)) return true;
+    }
+    return false;
+}
+
+// the farthest pair of the rotation: own slot 1 against slot 0 of lane gl ^ 32
+// (slot distance 65), closer than L - rm
+__device__ __forceinline__ bool far_partner_ok128(const DevModel &m,
+                                                  const double (&z)[2], int gl)
+{
+    const double zp = __shfl_xor(z[0], 32, 64);
+    const double d = (gl < 32) ? (z[1] - zp) + m.L : z[1] - zp;
+    return __builtin_amdgcn_ballot_w64(d >= m.L_minus_rm) == 0ull;
+}
+
+// One walker on an ascending row of 128 slots.  z[2]: the lane's particles
+// (slots 2 gl, 2 gl + 1); lds: 5 rows of 256 entries.
+template <typename R, bool WF, bool EN, bool REUSE>
+__device__ __forceinline__ void eval_sorted128(const DevModel &m,
+                                               const double (&z)[2], int gl,
+                                               double *lds, double (&F)[2],
+                                               double &E, double &logwf)
+{
+    constexpr int G = 64, NS = 128, ROW = 2 * NS;
+    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
+      *lZ = lS + 4 * ROW;
+    QMC_SECTION("tables+onebody");
+    Own64<R> o[2];
+    SortedOneBody ob[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+        sorted_particle_setup<R, WF, EN, REUSE, NS>(m, z[a], 2 * gl + a,
+                                                    (R *)lds, o[a], ob[a]);
+    if (!REUSE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    int nb_wave = 0;
+    const bool nb_counted = EN && !m.is_free && m.ob_table && m.uniform_barrier;
+    if (nb_counted)
+        nb_wave = __popcll(__ballot(ob[0].barrier)) +
+                  __popcll(__ballot(ob[1].barrier));
+    const R sin_rm = (R)m.sin_rm;
+    // particle b of the partner lane of step k: entry (NS + 2 gl) - 2 k + b
+    const R *pS = lS + NS + 2 * gl, *pC = lC + NS + 2 * gl,
+            *pSU = lSU + NS + 2 * gl, *pCU = lCU + NS + 2 * gl,
+            *pZ = lZ + NS + 2 * gl;
+
+    R Fr[2] = { (R)ob[0].ldz, (R)ob[1].ldz };  // drift: one-body + quotients
+    R T[2] = { 0, 0 };       // travelling sums for the partner lane's particles
+    R Qall = 0, Qs = 0;      // sum of q^2 over all / short pairs
+    R PS = 1, PL = 1;        // products: short factors f2, |Y| of all pairs
+    int eS = 0, eL = 0;
+    int ns = 0;              // short pairs (EN)
+
+    // a short-range pair of own particle `oa` with the partner's k2-table
+    // (bsu, bcu): numerator / denominator of the one-case form
+#define QMC_S128_SHORT_XY(oa, bsu, bcu, X, Y)                                 \
+    const R Y = (oa).c0 * (bcu) + (oa).s0 * (bsu);                            \
+    R X = 0;                                                                  \
+    if (EN) X = (oa).ks0 * (bcu) - (oa).kc0 * (bsu);
+    // a pair of a general step: class from the sine, short ones recomputed in
+    // an exec-masked region
+#define QMC_S128_XY(oa, cs, cc, sup, cup, X, Y, sh)                           \
+    const R Y##_s = (oa).s * (cc) - (oa).c * (cs);   /* sin(pi D' / L) >= 0 */ \
+    R X = 0;                                                                  \
+    if (EN) X = (oa).akc * (cc) + (oa).aks * (cs);                            \
+    const bool sh = q_abs(Y##_s) < sin_rm;           /* D' < rm */             \
+    R Y = Y##_s;                                                              \
+    if (sh) {                                                                 \
+        asm volatile("");                                                     \
+        const R bsu_ = *(sup), bcu_ = *(cup);                                 \
+        Y = (oa).c0 * bcu_ + (oa).s0 * bsu_;                                  \
+        if (EN) X = (oa).ks0 * bcu_ - (oa).kc0 * bsu_;                        \
+    }
+
+    // ---- k = 0: the pair inside the lane (slot 1 against slot 0) ----
+    QMC_SECTION("pairs_in_lane");
+    {
+        const R cs = (R)o[0].s, cc = (R)o[0].c;
+        QMC_S128_XY(o[1], cs, cc, pSU, pCU, X, Y, sh)
+        if (WF) { PL *= Y; if (sh) { asm volatile(""); PS *= Y; } }
+        if (EN) {
+            const R q = pair_div(X, Y);
+            Fr[1] += q; Fr[0] -= q;
+            Qall = q_fma(q, q, Qall);
+            ns += __popcll(__builtin_amdgcn_ballot_w64(sh));
+            if (sh) { asm volatile(""); Qs = q_fma(q, q, Qs); }
+        }
+    }
+
+    // ---- leading steps: all four pairs of every lane are short ----
+    QMC_SECTION("leading_short_steps");
+    int k = 1;
+    R Pl = 1;                // factors of the leading steps
+    R Ql = 0;
+#define QMC_S128_LEAD(su0, cu0, su1, cu1)                                     \
+    {                                                                         \
+        QMC_S128_SHORT_XY(o[0], su0, cu0, X00, Y00)                           \
+        QMC_S128_SHORT_XY(o[1], su0, cu0, X10, Y10)                           \
+        QMC_S128_SHORT_XY(o[0], su1, cu1, X01, Y01)                           \
+        QMC_S128_SHORT_XY(o[1], su1, cu1, X11, Y11)                           \
+        if (WF) Pl *= (Y00 * Y10) * (Y01 * Y11);                              \
+        if (EN) {                                                             \
+            const R q00 = pair_div(X00, Y00), q10 = pair_div(X10, Y10);       \
+            const R q01 = pair_div(X01, Y01), q11 = pair_div(X11, Y11);       \
+            Fr[0] += q00 + q01;                                               \
+            Fr[1] += q10 + q11;                                               \
+            T[0] -= q00 + q10;                                                \
+            T[1] -= q01 + q11;                                                \
+            Ql = q_fma(q00, q00, Ql); Ql = q_fma(q10, q10, Ql);               \
+            Ql = q_fma(q01, q01, Ql); Ql = q_fma(q11, q11, Ql);               \
+            T[0] = group_ror1<G>(T[0]);                                       \
+            T[1] = group_ror1<G>(T[1]);                                       \
+        }                                                                     \
+    }
+    {
+        // set A: step k, set B: step k + 1 (entries of both partner particles)
+        R asu0 = pSU[-2], acu0 = pCU[-2], asu1 = pSU[-1], acu1 = pCU[-1];
+        R az = pZ[-2];
+        R bsu0 = pSU[-4], bcu0 = pCU[-4], bsu1 = pSU[-3], bcu1 = pCU[-3];
+        R bz = pZ[-4];
+        // (the farthest pair of a step: own slot 1 against the partner's slot 0)
+        const R zt = o[1].zt;
+#pragma clang loop unroll(disable)
+        while (k < G / 2 - 2) {
+            if (__builtin_amdgcn_ballot_w64(az > zt) != ~0ull) break;
+            QMC_S128_LEAD(asu0, acu0, asu1, acu1)
+            asu0 = pSU[-2 * (k + 2)]; acu0 = pCU[-2 * (k + 2)];
+            asu1 = pSU[-2 * (k + 2) + 1]; acu1 = pCU[-2 * (k + 2) + 1];
+            az = pZ[-2 * (k + 2)];
+            ++k;
+            if (__builtin_amdgcn_ballot_w64(bz > zt) != ~0ull) break;
+            QMC_S128_LEAD(bsu0, bcu0, bsu1, bcu1)
+            bsu0 = pSU[-2 * (k + 2)]; bcu0 = pCU[-2 * (k + 2)];
+            bsu1 = pSU[-2 * (k + 2) + 1]; bcu1 = pCU[-2 * (k + 2) + 1];
+            bz = pZ[-2 * (k + 2)];
+            ++k;
+            if (WF) {
+                // (eight factors per trip)
+                int e = 0;
+                q_fold(Pl, e);
+                eS += e; eL += e;
+            }
+        }
+    }
+#undef QMC_S128_LEAD
+    // (these pairs belong to both products and both sums)
+    if (WF) { PS *= Pl; PL *= Pl; }
+    if (EN) { Qall += Ql; Qs += Ql; ns += 4 * (k - 1) * G; }
+
+    // ---- general steps ----
+    QMC_SECTION("rotation_loop_body");
+    // the four pairs of a step against partner tables (s0, c0), (s1, c1)
+#define QMC_S128_STEP(s0_, c0_, s1_, c1_, kk, LAST)                           \
+    {                                                                         \
+        const bool mine = !(LAST) || gl < G / 2;                              \
+        QMC_S128_XY(o[0], s0_, c0_, pSU - 2 * (kk), pCU - 2 * (kk), X00, Y00, h00)         \
+        QMC_S128_XY(o[1], s0_, c0_, pSU - 2 * (kk), pCU - 2 * (kk), X10, Y10, h10)         \
+        QMC_S128_XY(o[0], s1_, c1_, pSU - 2 * (kk) + 1, pCU - 2 * (kk) + 1, X01, Y01, h01) \
+        QMC_S128_XY(o[1], s1_, c1_, pSU - 2 * (kk) + 1, pCU - 2 * (kk) + 1, X11, Y11, h11) \
+        if (WF && mine) {                                                     \
+            PL *= (Y00 * Y10) * (Y01 * Y11);                                  \
+            if (h00) { asm volatile(""); PS *= Y00; }                         \
+            if (h10) { asm volatile(""); PS *= Y10; }                         \
+            if (h01) { asm volatile(""); PS *= Y01; }                         \
+            if (h11) { asm volatile(""); PS *= Y11; }                         \
+        }                                                                     \
+        if (EN) {                                                             \
+            const R q00 = pair_div(X00, Y00), q10 = pair_div(X10, Y10);       \
+            const R q01 = pair_div(X01, Y01), q11 = pair_div(X11, Y11);       \
+            Fr[0] += q00 + q01;                                               \
+            Fr[1] += q10 + q11;                                               \
+            if (!(LAST)) {                                                    \
+                T[0] -= q00 + q10;                                            \
+                T[1] -= q01 + q11;                                            \
+                T[0] = group_ror1<G>(T[0]);                                   \
+                T[1] = group_ror1<G>(T[1]);                                   \
+            }                                                                 \
+            ns += __popcll(__builtin_amdgcn_ballot_w64(h00 & mine)) +         \
+                  __popcll(__builtin_amdgcn_ballot_w64(h10 & mine)) +         \
+                  __popcll(__builtin_amdgcn_ballot_w64(h01 & mine)) +         \
+                  __popcll(__builtin_amdgcn_ballot_w64(h11 & mine));          \
+            if (mine) {                                                       \
+                Qall = q_fma(q00, q00, Qall); Qall = q_fma(q10, q10, Qall);   \
+                Qall = q_fma(q01, q01, Qall); Qall = q_fma(q11, q11, Qall);   \
+                if (h00) { asm volatile(""); Qs = q_fma(q00, q00, Qs); }      \
+                if (h10) { asm volatile(""); Qs = q_fma(q10, q10, Qs); }      \
+                if (h01) { asm volatile(""); Qs = q_fma(q01, q01, Qs); }      \
+                if (h11) { asm volatile(""); Qs = q_fma(q11, q11, Qs); }      \
+            }                                                                 \
+        }                                                                     \
+    }
+    {
+        R as0 = pS[-2 * k], ac0 = pC[-2 * k];
+        R as1 = pS[-2 * k + 1], ac1 = pC[-2 * k + 1];
+        R bs0 = pS[-2 * (k + 1)], bc0 = pC[-2 * (k + 1)];
+        R bs1 = pS[-2 * (k + 1) + 1], bc1 = pC[-2 * (k + 1) + 1];
+#pragma clang loop unroll(disable)
+        while (k < G / 2 - 1) {
+            QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
+            as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
+            as1 = pS[-2 * (k + 2) + 1]; ac1 = pC[-2 * (k + 2) + 1];
+            QMC_S128_STEP(bs0, bc0, bs1, bc1, k + 1, false)
+            // (k + 3 <= G/2 + 1: inside the doubled tables)
+            bs0 = pS[-2 * (k + 3)]; bc0 = pC[-2 * (k + 3)];
+            bs1 = pS[-2 * (k + 3) + 1]; bc1 = pC[-2 * (k + 3) + 1];
+            k += 2;
+            if (WF) {
+                q_fold(PS, eS);
+                q_fold(PL, eL);
+            }
+        }
+        if (k < G / 2) {
+            QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
+            ++k;
+            as0 = bs0; ac0 = bc0; as1 = bs1; ac1 = bc1;
+        }
+        // the final half step visits every pair from both sides
+        QMC_SECTION("rotation_last_step");
+        QMC_S128_STEP(as0, ac0, as1, ac1, k, true)
+    }
+#undef QMC_S128_STEP
+#undef QMC_S128_XY
+#undef QMC_S128_SHORT_XY
+    if (EN) {
+        Fr[0] += __shfl_xor(T[0], G / 2, 64);
+        Fr[1] += __shfl_xor(T[1], G / 2, 64);
+    }
+
+    QMC_SECTION("energy+logwf");
+    double e_lane = 0.0, e_consts = 0.0;
+    if (EN) {
+        F[0] = (double)Fr[0]; F[1] = (double)Fr[1];
+        const double Qall_d = (double)Qall, Qs_d = (double)Qs;
+        const double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
+        e_lane = fma(2.0, pk, ob[0].kin1 + ob[1].kin1) - F[0] * F[0] -
+                 F[1] * F[1];
+        if (nb_counted)
+            e_consts += (double)(NS - nb_wave) * m.e0 +
+                        (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
+        const int nl = NS * (NS - 1) / 2 - ns;
+        e_consts += 2.0 * (m.k2sq * (double)ns + m.b_long * (double)nl);
+    }
+    double lw = 0.0;
+    if (WF) {
+        const double LN2 = 0.693147180559945309417;
+        q_fold(PS, eS);
+        q_fold(PL, eL);
+        const double PS_d = (double)PS, PL_d = (double)PL;
+        if (!m.is_free && m.ob_table) {
+            const double lSv = log_pos(PS_d);
+            lw = fma(m.beta, log_pos(PL_d) - lSv, lSv);
+        } else {
+            lw = log_pos(ob[0].prod1 * ob[1].prod1 * PS_d) +
+                 m.beta * log_pos(fast_div(PL_d, PS_d));
+        }
+        lw += LN2 * ((double)eS + m.beta * (double)(eL - eS));
+        lw -= ob[0].xoff + ob[1].xoff;
+    }
+    // (two particles per lane: the sums over the lanes by DPP rotations and a
+    // butterfly, as eval_walker does for this shape -- the accumulators of
+    // the matrix instruction cost it a wave of occupancy)
+    if (EN) E = group_sum<G>(e_lane) + e_consts;
+    if (WF) logwf = group_sum<G>(lw);
+}

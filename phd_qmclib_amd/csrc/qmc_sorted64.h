@@ -137,6 +137,86 @@ struct Own64 {
     R zt;            // z - rm: a partner above it is closer than rm
 };
 
+// The one-body part of a particle (as in eval_walker).
+struct SortedOneBody {
+    double ldz = 0.0;     // f1'/f1
+    double kin1 = 0.0;    // -f1''/f1 + ldz^2 + V; ldz^2 alone when every barrier
+                          // is alike (the region constants are then counted
+                          // per wavefront from `barrier`)
+    double xoff = 0.0;    // -log f1 (WF)
+    double prod1 = 1.0;   // f1 itself on the direct path (WF)
+    bool barrier = false;
+};
+
+// Everything one particle (slot `slot` of NS, position z) contributes before
+// the pair loop: its one-body factor, its own pair tables `o`, and -- unless
+// the tables of this configuration are already there (REUSE) -- its entries of
+// the LDS tables: 5 rows of 2 NS entries (sin, cos(pi z / L), sin, cos(k2 z), z;
+// upper copy [NS + slot] = the particle, lower copy [slot] = the particle one
+// period below).
+template <typename R, bool WF, bool EN, bool REUSE, int NS>
+__device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double z,
+                                                      int slot, R *tab,
+                                                      Own64<R> &o,
+                                                      SortedOneBody &ob)
+{
+    constexpr int ROW = 2 * NS;
+    R *lS = tab, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
+      *lZ = lS + 4 * ROW;
+    TrigRow trow;
+    const bool trig_ok = !REUSE && m.trig_table && trig_tab_load(m, z, trow);
+    if (!m.is_free && m.ob_table) {
+        double lf = 0.0;
+        one_body_tab<WF, EN>(m, z, ob.ldz, lf, ob.barrier);
+        if (WF) ob.xoff = -lf;
+        if (EN) {
+            if (m.uniform_barrier)
+                ob.kin1 = ob.ldz * ob.ldz;
+            else
+                ob.kin1 = fma(ob.ldz, ob.ldz,
+                              one_body_kin_const(m, z, ob.barrier));
+        }
+    } else if (!m.is_free) {
+        double kp, f1, xo;
+        one_body(m, z, ob.ldz, kp, f1, xo);
+        if (EN) ob.kin1 = kp;
+        if (WF) { ob.prod1 = f1; ob.xoff = xo; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PTab ta;
+    if (REUSE) {
+        ta.s = (double)lS[NS + slot]; ta.c = (double)lC[NS + slot];
+        ta.su = (double)lSU[NS + slot]; ta.cu = (double)lCU[NS + slot];
+    } else if (trig_ok) {
+        trig_tab_finish(m, trow, ta);
+    } else {
+        sincos_halfpi(z * m.two_over_L, ta.s, ta.c);
+        sincos_halfpi(z * m.k2_2pi, ta.su, ta.cu);
+    }
+    o.s = (R)ta.s; o.c = (R)ta.c;
+    if (EN) {
+        o.aks = (R)(m.a_long * ta.s);
+        o.akc = (R)(m.a_long * ta.c);
+    }
+    const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
+    const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
+    o.s0 = (R)s0; o.c0 = (R)c0;
+    if (EN) {
+        o.ks0 = (R)(m.m_k2 * s0);
+        o.kc0 = (R)(m.m_k2 * c0);
+    }
+    o.zt = (R)(z - m.rm);
+    if (!REUSE) {
+        lS[NS + slot] = (R)ta.s; lC[NS + slot] = (R)ta.c;
+        lSU[NS + slot] = (R)ta.su; lCU[NS + slot] = (R)ta.cu;
+        lZ[NS + slot] = (R)z;
+        lS[slot] = (R)-ta.s; lC[slot] = (R)-ta.c;
+        lSU[slot] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
+        lCU[slot] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
+        lZ[slot] = (R)(z - m.L);
+    }
+}
+
 // One walker on ascending lanes.  z: the lane's particle; lds: 5 rows of 2 G
 // entries (sin, cos(pi z / L), sin, cos(k2 z), z; upper copy = the particle,
 // lower copy = the particle one period below).
@@ -151,76 +231,19 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     QMC_SECTION("tables+onebody");
-    // ---- one-body factor (as in eval_walker) ----
-    double ldz = 0.0;            // f1'/f1
-    double kin1 = 0.0;           // -f1''/f1 + ldz^2 + V (or ldz^2 alone, below)
-    double xoff = 0.0;           // -log f1 (WF)
-    double prod1 = 1.0;          // f1 itself on the direct path (WF)
-    int nb_wave = 0;             // particles inside a barrier (uniform barriers)
-    bool nb_counted = false;
-    TrigRow trow;
-    const bool trig_ok = !REUSE && m.trig_table && trig_tab_load(m, z, trow);
-    if (!m.is_free && m.ob_table) {
-        double lf = 0.0;
-        bool barrier;
-        one_body_tab<WF, EN>(m, z, ldz, lf, barrier);
-        if (WF) xoff = -lf;
-        if (EN) {
-            if (m.uniform_barrier) {
-                nb_wave = __popcll(__ballot(barrier));
-                nb_counted = true;
-                kin1 = ldz * ldz;
-            } else {
-                kin1 = fma(ldz, ldz, one_body_kin_const(m, z, barrier));
-            }
-        }
-    } else if (!m.is_free) {
-        double kp, f1, xo;
-        one_body(m, z, ldz, kp, f1, xo);
-        if (EN) kin1 = kp;
-        if (WF) { prod1 = f1; xoff = xo; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- pair tables ----
     Own64<R> o;
-    {
-        PTab ta;
-        if (REUSE) {
-            ta.s = (double)lS[G + gl]; ta.c = (double)lC[G + gl];
-            ta.su = (double)lSU[G + gl]; ta.cu = (double)lCU[G + gl];
-        } else if (trig_ok) {
-            trig_tab_finish(m, trow, ta);
-        } else {
-            sincos_halfpi(z * m.two_over_L, ta.s, ta.c);
-            sincos_halfpi(z * m.k2_2pi, ta.su, ta.cu);
-        }
-        o.s = (R)ta.s; o.c = (R)ta.c;
-        if (EN) {
-            o.aks = (R)(m.a_long * ta.s);
-            o.akc = (R)(m.a_long * ta.c);
-        }
-        const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
-        const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
-        o.s0 = (R)s0; o.c0 = (R)c0;
-        if (EN) {
-            o.ks0 = (R)(m.m_k2 * s0);
-            o.kc0 = (R)(m.m_k2 * c0);
-        }
-        o.zt = (R)(z - m.rm);
-        if (!REUSE) {
-            lS[G + gl] = (R)ta.s; lC[G + gl] = (R)ta.c;
-            lSU[G + gl] = (R)ta.su; lCU[G + gl] = (R)ta.cu;
-            lZ[G + gl] = (R)z;
-            lS[gl] = (R)-ta.s; lC[gl] = (R)-ta.c;
-            lSU[gl] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
-            lCU[gl] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
-            lZ[gl] = (R)(z - m.L);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+    SortedOneBody ob;
+    sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob);
+    if (!REUSE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    const double ldz = ob.ldz, kin1 = ob.kin1, xoff = ob.xoff,
+                 prod1 = ob.prod1;
+    int nb_wave = 0;
+    const bool nb_counted = EN && !m.is_free && m.ob_table && m.uniform_barrier;
+    if (nb_counted) nb_wave = __popcll(__ballot(ob.barrier));
     const R sin_rm = (R)m.sin_rm;
     // partner of rotation step k: entry (G + gl) - k
     const R *pS = lS + G + gl, *pC = lC + G + gl, *pSU = lSU + G + gl,

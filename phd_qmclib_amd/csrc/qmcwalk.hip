@@ -152,6 +152,14 @@ static size_t lds_bytes()
            sizeof(double);
 }
 
+// (the stepping kernels: StepLds, qmc_kernels.h)
+template <int G, int P, bool PAD, bool ZC>
+static size_t step_lds_bytes()
+{
+    return (size_t)(WalkBlock<G>::N / G) * StepLds<G, P, PAD, ZC>::DOUBLES *
+           sizeof(double);
+}
+
 // Dynamic LDS above the default limit must be opted into per kernel.
 template <typename K>
 static void allow_lds(K kernel, size_t bytes)
@@ -231,7 +239,7 @@ struct LaunchVmc {
     static constexpr bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const VmcArgs &a)
     {
-        const size_t lds = lds_bytes<G, P, ZC>();
+        const size_t lds = step_lds_bytes<G, P, PAD, ZC>();
         const bool lean = !a.tape && !a.gaussian && !a.ser_wf && !a.ser_e &&
                           !a.ser_stat && !a.ser_pos;
         ProfScope prof(e);
@@ -278,7 +286,7 @@ struct LaunchEvolve {
     static constexpr bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const EvolveArgs &a)
     {
-        const size_t lds = lds_bytes<G, P, ZC>();
+        const size_t lds = step_lds_bytes<G, P, PAD, ZC>();
         ProfScope prof(e);
         if constexpr (has_fast<G, ZC>()) {
             if (e->fast) {
