@@ -1278,11 +1278,9 @@ template <int G, int P, bool ZCLASS>
 struct GroupLds {
     static constexpr int DUP = (P >= 8) ? QMC_DUP8 : ((P >= 2) ? 1 : 2);
     static constexpr int ROW = DUP * G * P;
-    // (the one-walker-per-wavefront, one-particle-per-lane shape keeps the
-    // positions as a fifth row too: qmc_sorted64.h; 5 KB per wavefront = 32
-    // wavefronts in a CU's 160 KB)
-    static constexpr bool HAS_Z = ZCLASS || (QMC_SORTED64 && G == 64 && P == 1);
-    static constexpr int DOUBLES = (HAS_Z ? 5 : 4) * ROW;
+    // (the sorted-lane path of the one-particle-per-lane shape, qmc_sorted64.h,
+    // needs 5 rows of 96 entries: inside the 4 x 128 of this layout)
+    static constexpr int DOUBLES = (ZCLASS ? 5 : 4) * ROW;
 };
 
 // Evaluate one walker held in registers.

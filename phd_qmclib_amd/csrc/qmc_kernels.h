@@ -31,13 +31,13 @@ struct WalkBlock {
 };
 
 // LDS doubles per lane group of the stepping kernels (vmc_step, dmc_evolve):
-// the sorted-row path of the exact N = 128 shape keeps doubled tables and the
-// positions, 5 rows of 256 entries (qmc_sorted128.h)
+// the sorted-row path of the exact N = 128 shape keeps the positions as well,
+// 5 rows of 192 entries (qmc_sorted64.h: sorted_particle_setup)
 template <int G, int P, bool PAD, bool ZC>
 struct StepLds {
     static constexpr int DOUBLES =
         (QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC)
-            ? 5 * 2 * 128 : GroupLds<G, P, ZC>::DOUBLES;
+            ? 5 * (128 + 64) : GroupLds<G, P, ZC>::DOUBLES;
 };
 
 // a wave-uniform 64-bit value as the compiler can see it (scalar registers)
@@ -56,7 +56,14 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
 #ifndef QMC_LB_P1
 #define QMC_LB_P1 8
 #endif
+// (the sorted-row N = 128 shape: 7.5 KB of LDS per walker leaves room for five
+// wavefronts per SIMD, which takes <= 96 registers)
+#ifndef QMC_LB_DMC_P2
+#define QMC_LB_DMC_P2 5
+#endif
 #define QMC_LB_WAVES , ((G == 64 && P == 1) ? QMC_LB_P1 : 1)
+#define QMC_LB_WAVES_DMC , ((G == 64 && P == 1) ? QMC_LB_P1 \
+                            : (G == 64 && P == 2 && !PAD && !ZC) ? QMC_LB_DMC_P2 : 1)
 // (The VMC step of the exact N <= 128 shape held to 96 registers for a fifth
 // wave was 2.4 % faster with the four-case form; with the two-case form it needs
 // 108 registers unconstrained (4 waves) and the constraint costs 2.5 %: off.)
@@ -440,7 +447,7 @@ struct EvolveArgs {
 // Drift-diffusion + local energy of every child walker
 // (qmc_base/jastrow/dmc.py:758-825, 892-942).
 template <int G, int P, bool PAD, bool ZC, typename R = double>
-__global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES)
+__global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES_DMC)
 dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
 {
     // model constants live in device memory: scalar loads on demand keep the

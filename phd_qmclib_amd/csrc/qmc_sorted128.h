@@ -83,14 +83,15 @@ __device__ __forceinline__ bool far_partner_ok128(const DevModel &m,
 }
 
 // One walker on an ascending row of 128 slots.  z[2]: the lane's particles
-// (slots 2 gl, 2 gl + 1); lds: 5 rows of 256 entries.
+// (slots 2 gl, 2 gl + 1); lds: the 5 rows of sorted_particle_setup (192 entries
+// each).
 template <typename R, bool WF, bool EN, bool REUSE>
 __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                                                const double (&z)[2], int gl,
                                                double *lds, double (&F)[2],
                                                double &E, double &logwf)
 {
-    constexpr int G = 64, NS = 128, ROW = 2 * NS;
+    constexpr int G = 64, NS = 128, H = NS / 2, ROW = NS + H;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     QMC_SECTION("tables+onebody");
@@ -111,10 +112,10 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         nb_wave = __popcll(__ballot(ob[0].barrier)) +
                   __popcll(__ballot(ob[1].barrier));
     const R sin_rm = (R)m.sin_rm;
-    // particle b of the partner lane of step k: entry (NS + 2 gl) - 2 k + b
-    const R *pS = lS + NS + 2 * gl, *pC = lC + NS + 2 * gl,
-            *pSU = lSU + NS + 2 * gl, *pCU = lCU + NS + 2 * gl,
-            *pZ = lZ + NS + 2 * gl;
+    // particle b of the partner lane of step k: entry (H + 2 gl) - 2 k + b
+    const R *pS = lS + H + 2 * gl, *pC = lC + H + 2 * gl,
+            *pSU = lSU + H + 2 * gl, *pCU = lCU + H + 2 * gl,
+            *pZ = lZ + H + 2 * gl;
 
     R Fr[2] = { (R)ob[0].ldz, (R)ob[1].ldz };  // drift: one-body + quotients
     R T[2] = { 0, 0 };       // travelling sums for the partner lane's particles
@@ -261,13 +262,42 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             }                                                                 \
         }                                                                     \
     }
+    // ... and of a step whose four pairs are long-range for every lane: no
+    // classification, no exec-masked region
+#define QMC_S128_LONG_STEP(s0_, c0_, s1_, c1_)                                \
+    {                                                                         \
+        const R Y00 = o[0].s * (c0_) - o[0].c * (s0_);                        \
+        const R Y10 = o[1].s * (c0_) - o[1].c * (s0_);                        \
+        const R Y01 = o[0].s * (c1_) - o[0].c * (s1_);                        \
+        const R Y11 = o[1].s * (c1_) - o[1].c * (s1_);                        \
+        if (WF) PL *= (Y00 * Y10) * (Y01 * Y11);                              \
+        if (EN) {                                                             \
+            const R q00 = pair_div(o[0].akc * (c0_) + o[0].aks * (s0_), Y00); \
+            const R q10 = pair_div(o[1].akc * (c0_) + o[1].aks * (s0_), Y10); \
+            const R q01 = pair_div(o[0].akc * (c1_) + o[0].aks * (s1_), Y01); \
+            const R q11 = pair_div(o[1].akc * (c1_) + o[1].aks * (s1_), Y11); \
+            Fr[0] += q00 + q01;                                               \
+            Fr[1] += q10 + q11;                                               \
+            T[0] -= q00 + q10;                                                \
+            T[1] -= q01 + q11;                                                \
+            T[0] = group_ror1<G>(T[0]);                                       \
+            T[1] = group_ror1<G>(T[1]);                                       \
+            Qall = q_fma(q00, q00, Qall); Qall = q_fma(q10, q10, Qall);       \
+            Qall = q_fma(q01, q01, Qall); Qall = q_fma(q11, q11, Qall);       \
+        }                                                                     \
+    }
     {
         R as0 = pS[-2 * k], ac0 = pC[-2 * k];
         R as1 = pS[-2 * k + 1], ac1 = pC[-2 * k + 1];
         R bs0 = pS[-2 * (k + 1)], bc0 = pC[-2 * (k + 1)];
         R bs1 = pS[-2 * (k + 1) + 1], bc1 = pC[-2 * (k + 1) + 1];
+        // the nearest pair of a step: own slot 0 against the partner's slot 1;
+        // once it is long-range for every lane, so is every later pair
+        const R zt0 = o[0].zt;
 #pragma clang loop unroll(disable)
         while (k < G / 2 - 1) {
+            if (__builtin_amdgcn_ballot_w64(pZ[-2 * k + 1] > zt0) == 0ull)
+                break;
             QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
             as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
             as1 = pS[-2 * (k + 2) + 1]; ac1 = pC[-2 * (k + 2) + 1];
@@ -281,6 +311,19 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                 q_fold(PL, eL);
             }
         }
+        // ---- trailing steps: every pair is long-range ----
+        QMC_SECTION("rotation");
+#pragma clang loop unroll(disable)
+        while (k < G / 2 - 1) {
+            QMC_S128_LONG_STEP(as0, ac0, as1, ac1)
+            as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
+            as1 = pS[-2 * (k + 2) + 1]; ac1 = pC[-2 * (k + 2) + 1];
+            QMC_S128_LONG_STEP(bs0, bc0, bs1, bc1)
+            bs0 = pS[-2 * (k + 3)]; bc0 = pC[-2 * (k + 3)];
+            bs1 = pS[-2 * (k + 3) + 1]; bc1 = pC[-2 * (k + 3) + 1];
+            k += 2;
+            if (WF) q_fold(PL, eL);
+        }
         if (k < G / 2) {
             QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
             ++k;
@@ -291,6 +334,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         QMC_S128_STEP(as0, ac0, as1, ac1, k, true)
     }
 #undef QMC_S128_STEP
+#undef QMC_S128_LONG_STEP
 #undef QMC_S128_XY
 #undef QMC_S128_SHORT_XY
     if (EN) {

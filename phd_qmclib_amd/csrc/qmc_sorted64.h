@@ -151,16 +151,18 @@ struct SortedOneBody {
 // Everything one particle (slot `slot` of NS, position z) contributes before
 // the pair loop: its one-body factor, its own pair tables `o`, and -- unless
 // the tables of this configuration are already there (REUSE) -- its entries of
-// the LDS tables: 5 rows of 2 NS entries (sin, cos(pi z / L), sin, cos(k2 z), z;
-// upper copy [NS + slot] = the particle, lower copy [slot] = the particle one
-// period below).
+// the LDS tables: 5 rows (sin, cos(pi z / L), sin, cos(k2 z), z) of NS + NS/2
+// entries: [NS/2 + slot] = the particle, [slot - NS/2] = the particle one
+// period below, kept for the upper half of the slots only -- the rotation
+// reaches NS/2 slots down and no further (7.5 KB per walker at N = 128: five
+// wavefronts per SIMD; the full doubled tables allowed four).
 template <typename R, bool WF, bool EN, bool REUSE, int NS>
 __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double z,
                                                       int slot, R *tab,
                                                       Own64<R> &o,
                                                       SortedOneBody &ob)
 {
-    constexpr int ROW = 2 * NS;
+    constexpr int H = NS / 2, ROW = NS + H;
     R *lS = tab, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     TrigRow trow;
@@ -185,8 +187,8 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
     __builtin_amdgcn_sched_barrier(0);
     PTab ta;
     if (REUSE) {
-        ta.s = (double)lS[NS + slot]; ta.c = (double)lC[NS + slot];
-        ta.su = (double)lSU[NS + slot]; ta.cu = (double)lCU[NS + slot];
+        ta.s = (double)lS[H + slot]; ta.c = (double)lC[H + slot];
+        ta.su = (double)lSU[H + slot]; ta.cu = (double)lCU[H + slot];
     } else if (trig_ok) {
         trig_tab_finish(m, trow, ta);
     } else {
@@ -207,19 +209,20 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
     }
     o.zt = (R)(z - m.rm);
     if (!REUSE) {
-        lS[NS + slot] = (R)ta.s; lC[NS + slot] = (R)ta.c;
-        lSU[NS + slot] = (R)ta.su; lCU[NS + slot] = (R)ta.cu;
-        lZ[NS + slot] = (R)z;
-        lS[slot] = (R)-ta.s; lC[slot] = (R)-ta.c;
-        lSU[slot] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
-        lCU[slot] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
-        lZ[slot] = (R)(z - m.L);
+        lS[H + slot] = (R)ta.s; lC[H + slot] = (R)ta.c;
+        lSU[H + slot] = (R)ta.su; lCU[H + slot] = (R)ta.cu;
+        lZ[H + slot] = (R)z;
+        if (slot >= H) {
+            lS[slot - H] = (R)-ta.s; lC[slot - H] = (R)-ta.c;
+            lSU[slot - H] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
+            lCU[slot - H] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
+            lZ[slot - H] = (R)(z - m.L);
+        }
     }
 }
 
-// One walker on ascending lanes.  z: the lane's particle; lds: 5 rows of 2 G
-// entries (sin, cos(pi z / L), sin, cos(k2 z), z; upper copy = the particle,
-// lower copy = the particle one period below).
+// One walker on ascending lanes.  z: the lane's particle; lds: the 5 rows of
+// sorted_particle_setup (96 entries each).
 //   WF    : logwf out;   EN: E and F (drift of the lane's particle) out
 //   REUSE : the tables of this configuration are already in LDS
 template <typename R, bool WF, bool EN, bool REUSE>
@@ -227,7 +230,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                                               double *lds, double &F, double &E,
                                               double &logwf)
 {
-    constexpr int G = 64, ROW = 2 * G;
+    constexpr int G = 64, H = G / 2, ROW = G + H;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     QMC_SECTION("tables+onebody");
@@ -245,9 +248,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     const bool nb_counted = EN && !m.is_free && m.ob_table && m.uniform_barrier;
     if (nb_counted) nb_wave = __popcll(__ballot(ob.barrier));
     const R sin_rm = (R)m.sin_rm;
-    // partner of rotation step k: entry (G + gl) - k
-    const R *pS = lS + G + gl, *pC = lC + G + gl, *pSU = lSU + G + gl,
-            *pCU = lCU + G + gl, *pZ = lZ + G + gl;
+    // partner of rotation step k: entry (H + gl) - k
+    const R *pS = lS + H + gl, *pC = lC + H + gl, *pSU = lSU + H + gl,
+            *pCU = lCU + H + gl, *pZ = lZ + H + gl;
 
     R Fr = (R)ldz;           // drift: one-body term + pair quotients
     R T = 0;                 // travelling sum for the partner lane
