@@ -48,13 +48,16 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// Minimum waves per SIMD asked of the register allocator: the N <= 64 shape
-// needs 66 VGPRs left to itself (7 waves); held to 64 it spills one double and
-// runs 8 waves, +1.5 % on the VMC step (profiles/r02_ab_variants.txt).
+// Minimum waves per SIMD asked of the register allocator for the N <= 64
+// shape.  Round 2 held it to 64 registers (8 waves, one spilled double: +1.5 %
+// then).  With the sorted-lane path the kernel needs 70 left to itself (7
+// waves, no scratch) and 64 + 20 bytes of scratch at 8 waves; the two measure
+// the same (VMC 1.897 / 1.898 ms, DMC 0.522 / 0.519 ms, profiles/
+// r03_ab_variants.txt): the build without scratch ships.
 // (The N <= 128 shape held to 80 registers for 6 waves spills 56-140 bytes per
 // lane and loses 10-15 %.)
 #ifndef QMC_LB_P1
-#define QMC_LB_P1 8
+#define QMC_LB_P1 7
 #endif
 // (the sorted-row N = 128 shape: 7.5 KB of LDS per walker leaves room for five
 // wavefronts per SIMD, which takes <= 96 registers)
