@@ -36,8 +36,8 @@ struct WalkBlock {
 template <int G, int P, bool PAD, bool ZC>
 struct StepLds {
     static constexpr int DOUBLES =
-        (QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC)
-            ? 5 * (128 + 64) : GroupLds<G, P, ZC>::DOUBLES;
+        (QMC_SORTED128 && G == 64 && P == 2 && !ZC)
+            ? 5 * SortedRows<128>::ROW : GroupLds<G, P, ZC>::DOUBLES;
 };
 
 // a wave-uniform 64-bit value as the compiler can see it (scalar registers)
@@ -66,7 +66,7 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
 #endif
 #define QMC_LB_WAVES , ((G == 64 && P == 1) ? QMC_LB_P1 : 1)
 #define QMC_LB_WAVES_DMC , ((G == 64 && P == 1) ? QMC_LB_P1 \
-                            : (G == 64 && P == 2 && !PAD && !ZC) ? QMC_LB_DMC_P2 : 1)
+                            : (G == 64 && P == 2 && !ZC) ? QMC_LB_DMC_P2 : 1)
 // (The VMC step of the exact N <= 128 shape held to 96 registers for a fifth
 // wave was 2.4 % faster with the four-case form; with the two-case form it needs
 // 108 registers unconstrained (4 waves) and the constraint costs 2.5 %: off.)
@@ -277,15 +277,20 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // (one odd-even pass every QMC_RESORT_EVERY steps keeps the lanes sorted
     // well enough: a particle moves a few per cent of the spacing per step)
     // exactly ascending lanes: the fast pair sum of qmc_sorted64.h
-    constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !PAD && !ZC;
-    constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC;
+    // (33 <= N <= 63 as well: the ring then has N members)
+    constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !ZC;
+    // (66 <= N <= 126, N even, as well: N / 2 lanes with two particles each)
+    constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !ZC;
     bool fast = false;
     if constexpr (S64) {
-        fast = !m.is_ideal && sort_lanes64(zn[0], labn[0], gl) &&
-               far_partner_ok64(m, zn[0], gl);
+        fast = !m.is_ideal && sort_lanes64(zn[0], labn[0], gl, PAD ? n : 64) &&
+               (PAD ? far_partner_ok_ring(m, zn[0], gl, n)
+                    : far_partner_ok64(m, zn[0], gl));
     } else if constexpr (S128) {
-        fast = !m.is_ideal && sort_rows128(zn, labn, gl) &&
-               far_partner_ok128(m, zn, gl);
+        fast = !m.is_ideal && (!PAD || (n & 1) == 0) &&
+               sort_rows128(zn, labn, gl, PAD ? n / 2 : 64) &&
+               (PAD ? far_partner_ok_ring128(m, zn, gl, n / 2)
+                    : far_partner_ok128(m, zn, gl));
     } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         // ascending order, wrap point anchored at the lane seam (qmc_device.h)
         // (one particle per lane: lanes 0 .. n-1 hold them)
@@ -308,12 +313,12 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     double F[P], ei[P], e_new = 0.0, wf_new;
     if (S64 && fast) {
         if constexpr (S64)
-            eval_sorted64<R, true, !TWO_PASS, false>(m, zn[0], gl, lds, F[0],
-                                                     e_new, wf_new);
+            eval_sorted64<R, true, !TWO_PASS, false, PAD>(
+                m, zn[0], gl, lds, F[0], e_new, wf_new);
     } else if (S128 && fast) {
         if constexpr (S128)
-            eval_sorted128<R, true, !TWO_PASS, false>(m, zn, gl, lds, F, e_new,
-                                                      wf_new);
+            eval_sorted128<R, true, !TWO_PASS, false, PAD>(m, zn, gl, lds, F,
+                                                           e_new, wf_new);
     } else if constexpr (TWO_PASS)
         eval_walker<G, P, PAD, true, false, ZC, R, false, false>(
             m, zn, gl, lds, F, ei, e_new, wf_new);
@@ -363,12 +368,12 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             double wf_unused;
             if (S64 && fast) {
                 if constexpr (S64)
-                    eval_sorted64<R, false, true, true>(m, zn[0], gl, lds, F[0],
-                                                        e_new, wf_unused);
+                    eval_sorted64<R, false, true, true, PAD>(
+                        m, zn[0], gl, lds, F[0], e_new, wf_unused);
             } else if (S128 && fast) {
                 if constexpr (S128)
-                    eval_sorted128<R, false, true, true>(m, zn, gl, lds, F,
-                                                         e_new, wf_unused);
+                    eval_sorted128<R, false, true, true, PAD>(
+                        m, zn, gl, lds, F, e_new, wf_unused);
             } else
                 eval_walker<G, P, PAD, false, false, ZC, R, true, true>(
                     m, zn, gl, lds, F, ei, e_new, wf_unused);
@@ -519,15 +524,18 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         z[p] = zz;
     }
     QMC_SECTION("resort");
-    constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !PAD && !ZC;
-    constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !PAD && !ZC;
+    constexpr bool S64 = QMC_SORTED64 && G == 64 && P == 1 && !ZC;
+    constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !ZC;
     bool fast = false;
     if constexpr (S64) {
-        fast = !m.is_ideal && sort_lanes64(z[0], lab[0], gl) &&
-               far_partner_ok64(m, z[0], gl);
+        fast = !m.is_ideal && sort_lanes64(z[0], lab[0], gl, PAD ? n : 64) &&
+               (PAD ? far_partner_ok_ring(m, z[0], gl, n)
+                    : far_partner_ok64(m, z[0], gl));
     } else if constexpr (S128) {
-        fast = !m.is_ideal && sort_rows128(z, lab, gl) &&
-               far_partner_ok128(m, z, gl);
+        fast = !m.is_ideal && (!PAD || (n & 1) == 0) &&
+               sort_rows128(z, lab, gl, PAD ? n / 2 : 64) &&
+               (PAD ? far_partner_ok_ring128(m, z, gl, n / 2)
+                    : far_partner_ok128(m, z, gl));
     } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         anchor_seam(z[0], lab[0], n);
         if ((step % QMC_RESORT_EVERY) == 0)
@@ -551,11 +559,12 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     double F[P], ei[P], e_next, wf;
     if (S64 && fast) {
         if constexpr (S64)
-            eval_sorted64<R, false, true, false>(m, z[0], gl, lds, F[0], e_next,
-                                                 wf);
+            eval_sorted64<R, false, true, false, PAD>(m, z[0], gl, lds, F[0],
+                                                      e_next, wf);
     } else if (S128 && fast) {
         if constexpr (S128)
-            eval_sorted128<R, false, true, false>(m, z, gl, lds, F, e_next, wf);
+            eval_sorted128<R, false, true, false, PAD>(m, z, gl, lds, F,
+                                                       e_next, wf);
     } else
         eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei,
                                                     e_next, wf);

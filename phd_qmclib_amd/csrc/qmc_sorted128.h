@@ -24,29 +24,33 @@
 
 // ---- exact order of a row of 128 slots, two per lane ------------------------
 // ascending: z0 <= z1 inside every lane and z1 <= the next lane's z0
-__device__ __forceinline__ bool rows_ascending128(const double (&z)[2])
+__device__ __forceinline__ bool rows_ascending128(const double (&z)[2],
+                                                  int nl = 64)
 {
     // lane i takes the next lane's first slot (the last lane keeps its own)
     const int lo = __double2loint(z[0]), hi = __double2hiint(z[0]);
     const double up = __hiloint2double(
         __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false),
         __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));
-    const bool last = (threadIdx.x & 63) == 63;
-    const bool bad = (z[1] < z[0]) | (!last & (up < z[1]));
+    const int lane = threadIdx.x & 63;
+    const bool bad = (lane < nl) &
+                     ((z[1] < z[0]) | ((lane < nl - 1) & (up < z[1])));
     return __builtin_amdgcn_ballot_w64(bad) == 0ull;
 }
 
-__device__ __forceinline__ bool sort_rows128(double (&z)[2], int (&lab)[2], int gl)
+// (nl: lanes in use, each holding two particles)
+__device__ __forceinline__ bool sort_rows128(double (&z)[2], int (&lab)[2], int gl,
+                                             int nl = 64)
 {
-    if (rows_ascending128(z)) return true;
+    if (rows_ascending128(z, nl)) return true;
     const int lane = threadIdx.x & 63;
-    const int a_up = (lane == 63 ? lane : lane + 1) << 2;
-    const int a_dn = (lane == 0 ? lane : lane - 1) << 2;
+    const int a_up = (lane >= nl - 1 ? lane : lane + 1) << 2;
+    const int a_dn = (lane == 0 || lane >= nl ? lane : lane - 1) << 2;
     for (int it = 0; it < 66; ++it) {
-        anchor_seam_rows<2>(z, lab, 128);
+        anchor_seam_rows<2>(z, lab, 2 * nl);
         // even phase: the two slots of a lane
         {
-            const bool sw = z[1] < z[0];
+            const bool sw = lane < nl && z[1] < z[0];
             const double t = z[0]; const int u = lab[0];
             z[0] = sw ? z[1] : z[0]; lab[0] = sw ? lab[1] : lab[0];
             z[1] = sw ? t : z[1];    lab[1] = sw ? u : lab[1];
@@ -62,12 +66,12 @@ __device__ __forceinline__ bool sort_rows128(double (&z)[2], int (&lab)[2], int 
                 __builtin_amdgcn_ds_bpermute(a_dn, __double2hiint(z[1])),
                 __builtin_amdgcn_ds_bpermute(a_dn, __double2loint(z[1])));
             const int ldn = __builtin_amdgcn_ds_bpermute(a_dn, lab[1]);
-            const bool t_up = lane < 63 && up < z[1];
-            const bool t_dn = lane > 0 && dn > z[0];
+            const bool t_up = lane < nl - 1 && up < z[1];
+            const bool t_dn = lane > 0 && lane < nl && dn > z[0];
             z[1] = t_up ? up : z[1]; lab[1] = t_up ? lup : lab[1];
             z[0] = t_dn ? dn : z[0]; lab[0] = t_dn ? ldn : lab[0];
         }
-        if (rows_ascending128(z)) return true;
+        if (rows_ascending128(z, nl)) return true;
     }
     return false;
 }
@@ -82,25 +86,50 @@ __device__ __forceinline__ bool far_partner_ok128(const DevModel &m,
     return __builtin_amdgcn_ballot_w64(d >= m.L_minus_rm) == 0ull;
 }
 
+// the same for a ring of nl < 64 lanes
+__device__ __forceinline__ bool far_partner_ok_ring128(const DevModel &m,
+                                                       const double (&z)[2],
+                                                       int gl, int nl)
+{
+    const bool live = gl < nl;
+    int src = gl - nl / 2;
+    const bool wrapped = src < 0;
+    if (wrapped) src += nl;
+    const double zp = __shfl(z[0], live ? src : gl, 64);
+    const double d = wrapped ? (z[1] - zp) + m.L : z[1] - zp;
+    return __builtin_amdgcn_ballot_w64(live & (d >= m.L_minus_rm)) == 0ull;
+}
+
 // One walker on an ascending row of 128 slots.  z[2]: the lane's particles
 // (slots 2 gl, 2 gl + 1); lds: the 5 rows of sorted_particle_setup (192 entries
 // each).
-template <typename R, bool WF, bool EN, bool REUSE>
+//   PAD : N < 128 particles, N even: the first nl = N / 2 lanes hold two each
+//         (see eval_sorted64 for what changes on a ring shorter than the wave)
+template <typename R, bool WF, bool EN, bool REUSE, bool PAD = false>
 __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                                                const double (&z)[2], int gl,
                                                double *lds, double (&F)[2],
                                                double &E, double &logwf)
 {
-    constexpr int G = 64, NS = 128, H = NS / 2, ROW = NS + H;
+    constexpr int G = 64, NS = 128, H = SortedRows<NS>::H,
+                  ROW = SortedRows<NS>::ROW;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
+    const int n = PAD ? m.n : NS;            // particles (even)
+    const int nl = n / 2;                    // lanes in use
+    const int K = nl / 2;                    // rotation steps
+    const bool half_last = !PAD || (nl & 1) == 0;   // step K is a half step
+    const int kfull = half_last ? K - 1 : K;
+    const bool live = !PAD || gl < nl;
+    const unsigned long long live_mask =
+        PAD ? __builtin_amdgcn_ballot_w64(live) : ~0ull;
     QMC_SECTION("tables+onebody");
     Own64<R> o[2];
     SortedOneBody ob[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
         sorted_particle_setup<R, WF, EN, REUSE, NS>(m, z[a], 2 * gl + a,
-                                                    (R *)lds, o[a], ob[a]);
+                                                    (R *)lds, o[a], ob[a], n);
     if (!REUSE) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -109,14 +138,24 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     int nb_wave = 0;
     const bool nb_counted = EN && !m.is_free && m.ob_table && m.uniform_barrier;
     if (nb_counted)
-        nb_wave = __popcll(__ballot(ob[0].barrier)) +
-                  __popcll(__ballot(ob[1].barrier));
+        nb_wave = __popcll(__ballot(ob[0].barrier & live)) +
+                  __popcll(__ballot(ob[1].barrier & live));
     const R sin_rm = (R)m.sin_rm;
     // particle b of the partner lane of step k: entry (H + 2 gl) - 2 k + b
     const R *pS = lS + H + 2 * gl, *pC = lC + H + 2 * gl,
             *pSU = lSU + H + 2 * gl, *pCU = lCU + H + 2 * gl,
             *pZ = lZ + H + 2 * gl;
 
+    // the lane below in the ring of the lanes in use (travelling sums)
+    int ring_src = 0;
+    if (PAD) ring_src = (live ? (gl == 0 ? nl - 1 : gl - 1) : gl) << 2;
+#define QMC_S128_ROR(T)                                                       \
+    (PAD ? __hiloint2double(                                                  \
+               __builtin_amdgcn_ds_bpermute(ring_src, __double2hiint((double)(T))), \
+               __builtin_amdgcn_ds_bpermute(ring_src, __double2loint((double)(T)))) \
+         : (double)group_ror1<G>(T))
+#define QMC_S128_ALL(cond)                                                    \
+    ((__builtin_amdgcn_ballot_w64(cond) | ~live_mask) == ~0ull)
     R Fr[2] = { (R)ob[0].ldz, (R)ob[1].ldz };  // drift: one-body + quotients
     R T[2] = { 0, 0 };       // travelling sums for the partner lane's particles
     R Qall = 0, Qs = 0;      // sum of q^2 over all / short pairs
@@ -150,12 +189,13 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     {
         const R cs = (R)o[0].s, cc = (R)o[0].c;
         QMC_S128_XY(o[1], cs, cc, pSU, pCU, X, Y, sh)
+        // (the products of an idle lane never reach the sums: its log is dropped)
         if (WF) { PL *= Y; if (sh) { asm volatile(""); PS *= Y; } }
         if (EN) {
             const R q = pair_div(X, Y);
             Fr[1] += q; Fr[0] -= q;
             Qall = q_fma(q, q, Qall);
-            ns += __popcll(__builtin_amdgcn_ballot_w64(sh));
+            ns += __popcll(__builtin_amdgcn_ballot_w64(sh & live));
             if (sh) { asm volatile(""); Qs = q_fma(q, q, Qs); }
         }
     }
@@ -181,8 +221,8 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             T[1] -= q01 + q11;                                                \
             Ql = q_fma(q00, q00, Ql); Ql = q_fma(q10, q10, Ql);               \
             Ql = q_fma(q01, q01, Ql); Ql = q_fma(q11, q11, Ql);               \
-            T[0] = group_ror1<G>(T[0]);                                       \
-            T[1] = group_ror1<G>(T[1]);                                       \
+            T[0] = (R)QMC_S128_ROR(T[0]);                                     \
+            T[1] = (R)QMC_S128_ROR(T[1]);                                     \
         }                                                                     \
     }
     {
@@ -194,14 +234,14 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         // (the farthest pair of a step: own slot 1 against the partner's slot 0)
         const R zt = o[1].zt;
 #pragma clang loop unroll(disable)
-        while (k < G / 2 - 2) {
-            if (__builtin_amdgcn_ballot_w64(az > zt) != ~0ull) break;
+        while (k < kfull) {
+            if (!QMC_S128_ALL(az > zt)) break;
             QMC_S128_LEAD(asu0, acu0, asu1, acu1)
             asu0 = pSU[-2 * (k + 2)]; acu0 = pCU[-2 * (k + 2)];
             asu1 = pSU[-2 * (k + 2) + 1]; acu1 = pCU[-2 * (k + 2) + 1];
             az = pZ[-2 * (k + 2)];
             ++k;
-            if (__builtin_amdgcn_ballot_w64(bz > zt) != ~0ull) break;
+            if (!QMC_S128_ALL(bz > zt)) break;
             QMC_S128_LEAD(bsu0, bcu0, bsu1, bcu1)
             bsu0 = pSU[-2 * (k + 2)]; bcu0 = pCU[-2 * (k + 2)];
             bsu1 = pSU[-2 * (k + 2) + 1]; bcu1 = pCU[-2 * (k + 2) + 1];
@@ -218,14 +258,14 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
 #undef QMC_S128_LEAD
     // (these pairs belong to both products and both sums)
     if (WF) { PS *= Pl; PL *= Pl; }
-    if (EN) { Qall += Ql; Qs += Ql; ns += 4 * (k - 1) * G; }
+    if (EN) { Qall += Ql; Qs += Ql; ns += 4 * (k - 1) * nl; }
 
     // ---- general steps ----
     QMC_SECTION("rotation_loop_body");
     // the four pairs of a step against partner tables (s0, c0), (s1, c1)
 #define QMC_S128_STEP(s0_, c0_, s1_, c1_, kk, LAST)                           \
     {                                                                         \
-        const bool mine = !(LAST) || gl < G / 2;                              \
+        const bool mine = live & (!(LAST) || gl < K);                         \
         QMC_S128_XY(o[0], s0_, c0_, pSU - 2 * (kk), pCU - 2 * (kk), X00, Y00, h00)         \
         QMC_S128_XY(o[1], s0_, c0_, pSU - 2 * (kk), pCU - 2 * (kk), X10, Y10, h10)         \
         QMC_S128_XY(o[0], s1_, c1_, pSU - 2 * (kk) + 1, pCU - 2 * (kk) + 1, X01, Y01, h01) \
@@ -245,8 +285,8 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             if (!(LAST)) {                                                    \
                 T[0] -= q00 + q10;                                            \
                 T[1] -= q01 + q11;                                            \
-                T[0] = group_ror1<G>(T[0]);                                   \
-                T[1] = group_ror1<G>(T[1]);                                   \
+                T[0] = (R)QMC_S128_ROR(T[0]);                                 \
+                T[1] = (R)QMC_S128_ROR(T[1]);                                 \
             }                                                                 \
             ns += __popcll(__builtin_amdgcn_ballot_w64(h00 & mine)) +         \
                   __popcll(__builtin_amdgcn_ballot_w64(h10 & mine)) +         \
@@ -270,7 +310,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         const R Y10 = o[1].s * (c0_) - o[1].c * (s0_);                        \
         const R Y01 = o[0].s * (c1_) - o[0].c * (s1_);                        \
         const R Y11 = o[1].s * (c1_) - o[1].c * (s1_);                        \
-        if (WF) PL *= (Y00 * Y10) * (Y01 * Y11);                              \
+        if (WF && live) PL *= (Y00 * Y10) * (Y01 * Y11);                      \
         if (EN) {                                                             \
             const R q00 = pair_div(o[0].akc * (c0_) + o[0].aks * (s0_), Y00); \
             const R q10 = pair_div(o[1].akc * (c0_) + o[1].aks * (s0_), Y10); \
@@ -280,8 +320,8 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             Fr[1] += q10 + q11;                                               \
             T[0] -= q00 + q10;                                                \
             T[1] -= q01 + q11;                                                \
-            T[0] = group_ror1<G>(T[0]);                                       \
-            T[1] = group_ror1<G>(T[1]);                                       \
+            T[0] = (R)QMC_S128_ROR(T[0]);                                     \
+            T[1] = (R)QMC_S128_ROR(T[1]);                                     \
             Qall = q_fma(q00, q00, Qall); Qall = q_fma(q10, q10, Qall);       \
             Qall = q_fma(q01, q01, Qall); Qall = q_fma(q11, q11, Qall);       \
         }                                                                     \
@@ -295,8 +335,9 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         // once it is long-range for every lane, so is every later pair
         const R zt0 = o[0].zt;
 #pragma clang loop unroll(disable)
-        while (k < G / 2 - 1) {
-            if (__builtin_amdgcn_ballot_w64(pZ[-2 * k + 1] > zt0) == 0ull)
+        while (k < kfull) {
+            if (__builtin_amdgcn_ballot_w64(live & (pZ[-2 * k + 1] > zt0)) ==
+                0ull)
                 break;
             QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
             as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
@@ -314,7 +355,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         // ---- trailing steps: every pair is long-range ----
         QMC_SECTION("rotation");
 #pragma clang loop unroll(disable)
-        while (k < G / 2 - 1) {
+        while (k < kfull) {
             QMC_S128_LONG_STEP(as0, ac0, as1, ac1)
             as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
             as1 = pS[-2 * (k + 2) + 1]; ac1 = pC[-2 * (k + 2) + 1];
@@ -324,23 +365,35 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             k += 2;
             if (WF) q_fold(PL, eL);
         }
-        if (k < G / 2) {
+        if (k <= kfull) {
             QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
             ++k;
             as0 = bs0; ac0 = bc0; as1 = bs1; ac1 = bc1;
         }
-        // the final half step visits every pair from both sides
+        // the final half step (an even number of lanes in use) visits every
+        // pair from both sides
         QMC_SECTION("rotation_last_step");
-        QMC_S128_STEP(as0, ac0, as1, ac1, k, true)
+        if (half_last) QMC_S128_STEP(as0, ac0, as1, ac1, k, true)
     }
 #undef QMC_S128_STEP
 #undef QMC_S128_LONG_STEP
 #undef QMC_S128_XY
 #undef QMC_S128_SHORT_XY
     if (EN) {
-        Fr[0] += __shfl_xor(T[0], G / 2, 64);
-        Fr[1] += __shfl_xor(T[1], G / 2, 64);
+        // after kfull rotations lane l holds the sums of lane l - kfull - 1
+        if (PAD) {
+            int src = gl + kfull + 1;
+            if (src >= nl) src -= nl;
+            src = live ? src : gl;
+            Fr[0] += __shfl(T[0], src, 64);
+            Fr[1] += __shfl(T[1], src, 64);
+        } else {
+            Fr[0] += __shfl_xor(T[0], G / 2, 64);
+            Fr[1] += __shfl_xor(T[1], G / 2, 64);
+        }
     }
+#undef QMC_S128_ROR
+#undef QMC_S128_ALL
 
     QMC_SECTION("energy+logwf");
     double e_lane = 0.0, e_consts = 0.0;
@@ -350,11 +403,12 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         const double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
         e_lane = fma(2.0, pk, ob[0].kin1 + ob[1].kin1) - F[0] * F[0] -
                  F[1] * F[1];
+        if (PAD && !live) e_lane = 0.0;
         if (nb_counted)
-            e_consts += (double)(NS - nb_wave) * m.e0 +
+            e_consts += (double)(n - nb_wave) * m.e0 +
                         (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
-        const int nl = NS * (NS - 1) / 2 - ns;
-        e_consts += 2.0 * (m.k2sq * (double)ns + m.b_long * (double)nl);
+        const int nlong = n * (n - 1) / 2 - ns;
+        e_consts += 2.0 * (m.k2sq * (double)ns + m.b_long * (double)nlong);
     }
     double lw = 0.0;
     if (WF) {
@@ -371,6 +425,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         }
         lw += LN2 * ((double)eS + m.beta * (double)(eL - eS));
         lw -= ob[0].xoff + ob[1].xoff;
+        if (PAD && !live) lw = 0.0;
     }
     // (two particles per lane: the sums over the lanes by DPP rotations and a
     // butterfly, as eval_walker does for this shape -- the accumulators of

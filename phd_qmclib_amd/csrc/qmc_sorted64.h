@@ -47,10 +47,11 @@ __device__ __forceinline__ double wave_shr1_f64(double v)
         __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false));
 }
 
-// true iff the 64 lanes hold ascending positions (wave-uniform)
-__device__ __forceinline__ bool lanes_ascending64(double z)
+// true iff the first nl lanes hold ascending positions (wave-uniform)
+__device__ __forceinline__ bool lanes_ascending64(double z, int nl = 64)
 {
-    return __builtin_amdgcn_ballot_w64(z < wave_shr1_f64(z)) == 0ull;
+    const bool live = (int)(threadIdx.x & 63) < nl;
+    return __builtin_amdgcn_ballot_w64(live & (z < wave_shr1_f64(z))) == 0ull;
 }
 
 // One compare-exchange pass: every lane against the lane at byte address
@@ -79,22 +80,26 @@ __device__ __forceinline__ void cmpxchg_pass64(double &z, int &lab, int addr,
 // boundary sits at the wrong end of the row and is rotated into place instead
 // of being bubbled through 63 lanes.  Bounded: odd-even transposition sorts n
 // items in n passes.
-__device__ __forceinline__ bool sort_lanes64(double &z, int &lab, int gl)
+// (nl: lanes holding particles; the lanes above them never take part)
+__device__ __forceinline__ bool sort_lanes64(double &z, int &lab, int gl,
+                                             int nl = 64)
 {
-    if (lanes_ascending64(z)) return true;
+    if (lanes_ascending64(z, nl)) return true;
     // partners of the even pass (0,1)(2,3).. and of the odd pass (1,2)(3,4)..
-    // (lanes 0 and 63 sit the odd pass out: their partner is themselves)
+    // (a lane without a partner inside the row -- lane 0 and the last one in
+    // the odd pass -- is its own partner and keeps its particle)
     const int odd = gl & 1;
-    const int addr_even = (gl ^ 1) << 2;
+    const int pe = gl ^ 1;
+    const int addr_even = ((gl >= nl || pe >= nl) ? gl : pe) << 2;
     const int po = odd ? (gl + 1) : (gl - 1);
-    const int addr_odd = ((po < 0 || po > 63) ? gl : po) << 2;
+    const int addr_odd = ((gl >= nl || po < 0 || po >= nl) ? gl : po) << 2;
     const int flip_even = odd << 31;            // the odd lane is the upper one
     const int flip_odd = (odd ^ 1) << 31;       // the even lane is
     for (int it = 0; it < 34; ++it) {
-        anchor_seam(z, lab, 64);
+        anchor_seam(z, lab, nl);
         cmpxchg_pass64(z, lab, addr_even, flip_even);
         cmpxchg_pass64(z, lab, addr_odd, flip_odd);
-        if (lanes_ascending64(z)) return true;
+        if (lanes_ascending64(z, nl)) return true;
     }
     return false;
 }
@@ -109,6 +114,21 @@ __device__ __forceinline__ bool far_partner_ok64(const DevModel &m, double z,
     // D' = z - zp for the upper half of the lanes, z - (zp - L) for the lower
     const double d = (gl < 32) ? (z - zp) + m.L : z - zp;
     return __builtin_amdgcn_ballot_w64(d >= m.L_minus_rm) == 0ull;
+}
+
+// The same for a row of nl < 64 lanes: the partner of the last step, nl / 2
+// lanes down the ring.
+__device__ __forceinline__ bool far_partner_ok_ring(const DevModel &m, double z,
+                                                    int gl, int nl)
+{
+    const int K = nl / 2;
+    const bool live = gl < nl;
+    int src = gl - K;
+    const bool wrapped = src < 0;
+    if (wrapped) src += nl;
+    const double zp = __shfl(z, live ? src : gl, 64);
+    const double d = wrapped ? (z - zp) + m.L : z - zp;
+    return __builtin_amdgcn_ballot_w64(live & (d >= m.L_minus_rm)) == 0ull;
 }
 
 // A table read that stays where it is written: the loops below request the
@@ -152,17 +172,27 @@ struct SortedOneBody {
 // the pair loop: its one-body factor, its own pair tables `o`, and -- unless
 // the tables of this configuration are already there (REUSE) -- its entries of
 // the LDS tables: 5 rows (sin, cos(pi z / L), sin, cos(k2 z), z) of NS + NS/2
-// entries: [NS/2 + slot] = the particle, [slot - NS/2] = the particle one
-// period below, kept for the upper half of the slots only -- the rotation
-// reaches NS/2 slots down and no further (7.5 KB per walker at N = 128: five
-// wavefronts per SIMD; the full doubled tables allowed four).
+// (+ 1) entries: [H + slot] = the particle, [H + slot - n] = the particle one
+// period below, kept for the upper slots only -- the rotation reaches NS/2
+// slots down and no further (7.5 KB per walker at N = 128: five wavefronts per
+// SIMD; the full doubled tables allowed four).
+// `n`: slots in use (n = NS for the exact shapes; a slot >= n writes nothing).
+// The rows carry one unused entry in front: the loops request tables up to one
+// step past their last one.
+template <int NS>
+struct SortedRows {
+    static constexpr int H = NS / 2 + 1;       // offset of slot 0
+    static constexpr int ROW = NS + H;
+};
+
 template <typename R, bool WF, bool EN, bool REUSE, int NS>
 __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double z,
                                                       int slot, R *tab,
                                                       Own64<R> &o,
-                                                      SortedOneBody &ob)
+                                                      SortedOneBody &ob,
+                                                      int n = NS)
 {
-    constexpr int H = NS / 2, ROW = NS + H;
+    constexpr int H = SortedRows<NS>::H, ROW = SortedRows<NS>::ROW;
     R *lS = tab, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     TrigRow trow;
@@ -208,35 +238,50 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         o.kc0 = (R)(m.m_k2 * c0);
     }
     o.zt = (R)(z - m.rm);
-    if (!REUSE) {
+    if (!REUSE && slot < n) {
         lS[H + slot] = (R)ta.s; lC[H + slot] = (R)ta.c;
         lSU[H + slot] = (R)ta.su; lCU[H + slot] = (R)ta.cu;
         lZ[H + slot] = (R)z;
-        if (slot >= H) {
-            lS[slot - H] = (R)-ta.s; lC[slot - H] = (R)-ta.c;
-            lSU[slot - H] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
-            lCU[slot - H] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
-            lZ[slot - H] = (R)(z - m.L);
+        // one period below: the entry the slots up to NS / 2 above the start
+        // of the row find when they look past slot 0
+        const int lo = H + slot - n;
+        if (lo >= 1) {
+            lS[lo] = (R)-ta.s; lC[lo] = (R)-ta.c;
+            lSU[lo] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
+            lCU[lo] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
+            lZ[lo] = (R)(z - m.L);
         }
     }
 }
 
 // One walker on ascending lanes.  z: the lane's particle; lds: the 5 rows of
-// sorted_particle_setup (96 entries each).
+// sorted_particle_setup (97 entries each).
 //   WF    : logwf out;   EN: E and F (drift of the lane's particle) out
 //   REUSE : the tables of this configuration are already in LDS
-template <typename R, bool WF, bool EN, bool REUSE>
+//   PAD   : only the first nl = N < 64 lanes hold particles.  The ring then has
+//           nl members: nl / 2 rotation steps, the last of them a half step
+//           only if nl is even; the travelling sum moves through ds_bpermute
+//           (no DPP rotation over a partial wavefront), and every wave-wide
+//           test and count is restricted to the lanes in use.
+template <typename R, bool WF, bool EN, bool REUSE, bool PAD = false>
 __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int gl,
                                               double *lds, double &F, double &E,
                                               double &logwf)
 {
-    constexpr int G = 64, H = G / 2, ROW = G + H;
+    constexpr int G = 64, H = SortedRows<G>::H, ROW = SortedRows<G>::ROW;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
+    const int nl = PAD ? m.n : G;            // lanes in use = particles
+    const int K = nl / 2;                    // rotation steps
+    const bool half_last = !PAD || (nl & 1) == 0;   // step K is a half step
+    const int kfull = half_last ? K - 1 : K; // steps that visit a pair once
+    const bool live = !PAD || gl < nl;
+    const unsigned long long live_mask =
+        PAD ? __builtin_amdgcn_ballot_w64(live) : ~0ull;
     QMC_SECTION("tables+onebody");
     Own64<R> o;
     SortedOneBody ob;
-    sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob);
+    sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob, nl);
     if (!REUSE) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -246,11 +291,19 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                  prod1 = ob.prod1;
     int nb_wave = 0;
     const bool nb_counted = EN && !m.is_free && m.ob_table && m.uniform_barrier;
-    if (nb_counted) nb_wave = __popcll(__ballot(ob.barrier));
+    if (nb_counted) nb_wave = __popcll(__ballot(ob.barrier & live));
     const R sin_rm = (R)m.sin_rm;
     // partner of rotation step k: entry (H + gl) - k
     const R *pS = lS + H + gl, *pC = lC + H + gl, *pSU = lSU + H + gl,
             *pCU = lCU + H + gl, *pZ = lZ + H + gl;
+    // the lane below in the ring of the lanes in use (travelling sums)
+    int ring_src = 0;
+    if (PAD) ring_src = (live ? (gl == 0 ? nl - 1 : gl - 1) : gl) << 2;
+#define QMC_S64_ROR(T)                                                        \
+    (PAD ? __hiloint2double(                                                  \
+               __builtin_amdgcn_ds_bpermute(ring_src, __double2hiint((double)(T))), \
+               __builtin_amdgcn_ds_bpermute(ring_src, __double2loint((double)(T)))) \
+         : (double)group_ror1<G>(T))
 
     R Fr = (R)ldz;           // drift: one-body term + pair quotients
     R T = 0;                 // travelling sum for the partner lane
@@ -278,20 +331,23 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     {                                                                         \
         Fr += (q);                                                            \
         T -= (q);                                                             \
-        T = group_ror1<G>(T);                                                 \
+        T = (R)QMC_S64_ROR(T);                                                \
     }
+    // every lane in use says yes
+#define QMC_S64_ALL(cond)                                                     \
+    ((__builtin_amdgcn_ballot_w64(cond) | ~live_mask) == ~0ull)
     {
         R asu = lds_ahead(pSU - 1), acu = lds_ahead(pCU - 1), az = lds_ahead(pZ - 1);
         R bsu = lds_ahead(pSU - 2), bcu = lds_ahead(pCU - 2), bz = lds_ahead(pZ - 2);
-        // (k odd at the top; k + 3 <= G/2 + 1: inside the doubled tables)
+        // (k odd at the top; both steps of a trip are full steps)
 #pragma clang loop unroll(disable)
-        while (k < G / 2 - 2) {
-            if (__builtin_amdgcn_ballot_w64(az > o.zt) != ~0ull) break;
+        while (k < kfull) {
+            if (!QMC_S64_ALL(az > o.zt)) break;
             QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
             asu = lds_ahead(pSU - (k + 2)); acu = lds_ahead(pCU - (k + 2));
             az = lds_ahead(pZ - (k + 2));
             ++k;
-            if (__builtin_amdgcn_ballot_w64(bz > o.zt) != ~0ull) {
+            if (!QMC_S64_ALL(bz > o.zt)) {
                 if (EN) {
                     const R q = pair_div(Xa, Ya);
                     QMC_S64_ADD_Q(q)
@@ -319,7 +375,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
 #undef QMC_S64_LEAD_XY
     // (these pairs belong to both products and both sums)
     if (WF) { PL = PS; eL = eS; }
-    if (EN) { Qall = Qs; ns = (k - 1) * G; }
+    if (EN) { Qall = Qs; ns = (k - 1) * nl; }
 
     // ---- general steps: classified pair by pair ----
     QMC_SECTION("rotation_loop_body");
@@ -328,7 +384,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     const R Y##_s = o.s * (cc) - o.c * (cs);   /* sin(pi D' / L) >= 0 */       \
     R X = 0;                                                                  \
     if (EN) X = o.akc * (cc) + o.aks * (cs);   /* a_long cos(pi D' / L) */     \
-    const bool mine = !(LAST) || gl < G / 2;                                  \
+    const bool mine = live & (!(LAST) || gl < K);                             \
     const bool sh = q_abs(Y##_s) < sin_rm;     /* D' < rm */                   \
     if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));           \
     R Y = Y##_s;                                                              \
@@ -351,20 +407,17 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     }
     {
         R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k);   // step k
-        // step k + 1 (<= G/2)
+        // step k + 1 (<= K + 1: inside the rows)
         R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1));
 #pragma clang loop unroll(disable)
-        while (k < G / 2 - 1) {
+        while (k < kfull) {
             QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
             as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
             QMC_S64_XY(bs_, bc_, k + 1, false, Xb, Yb, shb, mineb)
-            // (k + 3 <= G/2 + 1: inside the doubled tables)
+            // (k + 3 <= K + 2: the unused entry in front of the rows)
             bs_ = lds_ahead(pS - (k + 3)); bc_ = lds_ahead(pC - (k + 3));
             k += 2;
             if (EN) {
-                // (one reciprocal for both quotients -- r = 1 / (Ya Yb), qa = Xa r
-                // Yb -- measured no faster, 1 % slower in the VMC step: the
-                // reciprocal does not hold up the multiply-add pipe)
                 const R qa = pair_div(Xa, Ya), qb = pair_div(Xb, Yb);
                 QMC_S64_ADD_Q(qa)
                 QMC_S64_ADD_Q(qb)
@@ -376,8 +429,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                 q_fold(PL, eL);
             }
         }
-        if (k < G / 2) {
-            // an odd number of steps was left: step G/2 - 1 is in the first set
+        if (k <= kfull) {
+            // an odd number of full steps was left: the last one is in the
+            // first set
             QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
             if (EN) {
                 const R q = pair_div(Xa, Ya);
@@ -387,20 +441,34 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
             ++k;
             as_ = bs_; ac_ = bc_;
         }
-        // the final half step visits every pair from both sides: each side
-        // updates its own particle, the lower half of the lanes tallies
+        // the final half step (an even number of lanes in use) visits every
+        // pair from both sides: each side updates its own particle, the lower
+        // half of the lanes tallies
         QMC_SECTION("rotation_last_step");
-        QMC_S64_XY(as_, ac_, k, true, Xl, Yl, shl, minel)
-        if (EN) {
-            const R q = pair_div(Xl, Yl);
-            Fr += q;
-            QMC_S64_TALLY(q, shl, minel)
+        if (half_last) {
+            QMC_S64_XY(as_, ac_, k, true, Xl, Yl, shl, minel)
+            if (EN) {
+                const R q = pair_div(Xl, Yl);
+                Fr += q;
+                QMC_S64_TALLY(q, shl, minel)
+            }
         }
     }
 #undef QMC_S64_XY
 #undef QMC_S64_TALLY
 #undef QMC_S64_ADD_Q
-    if (EN) Fr += __shfl_xor(T, G / 2, 64);
+#undef QMC_S64_ALL
+    if (EN) {
+        // after kfull rotations lane l holds the sum of particle l - kfull - 1
+        if (PAD) {
+            int src = gl + kfull + 1;
+            if (src >= nl) src -= nl;
+            Fr += __shfl(T, live ? src : gl, 64);
+        } else {
+            Fr += __shfl_xor(T, G / 2, 64);
+        }
+    }
+#undef QMC_S64_ROR
 
     QMC_SECTION("energy+logwf");
     double e_lane = 0.0, e_consts = 0.0;
@@ -409,11 +477,12 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         const double Qall_d = (double)Qall, Qs_d = (double)Qs;
         const double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
         e_lane = fma(2.0, pk, kin1) - F * F;
+        if (PAD && !live) e_lane = 0.0;
         if (nb_counted)
-            e_consts += (double)(G - nb_wave) * m.e0 +
+            e_consts += (double)(nl - nb_wave) * m.e0 +
                         (double)nb_wave * (m.v_barrier - m.v0_minus_e0);
-        const int nl = G * (G - 1) / 2 - ns;
-        e_consts += 2.0 * (m.k2sq * (double)ns + m.b_long * (double)nl);
+        const int nlong = nl * (nl - 1) / 2 - ns;
+        e_consts += 2.0 * (m.k2sq * (double)ns + m.b_long * (double)nlong);
     }
     double lw = 0.0;
     if (WF) {
@@ -429,6 +498,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         if (sizeof(R) == 4)
             lw += LN2 * ((double)eS + m.beta * (double)(eL - eS));
         lw -= xoff;
+        if (PAD && !live) lw = 0.0;
     }
     if (WF && EN) {
         wave_sum2_mfma(e_lane, lw, E, logwf);

@@ -212,12 +212,17 @@ def test_large_n_sampling_runs():
     v.close(); eng.close()
 
 
-@pytest.mark.parametrize('n', [100, 128, 130, 256, 300, 512])
+@pytest.mark.parametrize('n', [37, 48, 63, 66, 100, 101, 126, 128, 130, 256,
+                               300, 512])
 def test_large_shapes_trajectories_vs_oracle(oracle, n):
-    """Every lane-group shape above N = 64 -- (64,2), (64,4), (64,8), exact
-    and padded, i.e. the single-copy LDS tables, the two-pass own-particle
-    scheme and the masked variants -- through the VMC and DMC kernels, against
-    the oracle on the same Philox streams."""
+    """Every lane-group shape of one walker per wavefront -- (64,1) padded,
+    (64,2), (64,4), (64,8), exact and padded -- through the VMC and DMC
+    kernels, against the oracle on the same Philox streams.  The sorted-row
+    paths (qmc_sorted64.h, qmc_sorted128.h) on rings shorter than the
+    wavefront: N = 37, 63 (odd: no half step), 48; N = 66, 126 (an odd number
+    of lanes in use), 100; N = 101 (odd: the general path); above 128 the
+    single-copy LDS tables, the two-pass own-particle scheme and the masked
+    variants."""
     from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
     spec = box(n)
     m = oracle.model_from_cfc(spec.cfc_spec)
@@ -252,7 +257,7 @@ def test_large_shapes_trajectories_vs_oracle(oracle, n):
     eng.close()
 
 
-@pytest.mark.parametrize('n', [37, 64, 100, 101, 128, 300, 512])
+@pytest.mark.parametrize('n', [37, 48, 64, 66, 100, 101, 128, 300, 512])
 def test_long_trajectories_across_the_box_boundary(oracle, n):
     """Lane order is kept ascending with the place where positions wrap from L
     to 0 anchored at the end of the row (`anchor_seam`, `anchor_seam_rows`):

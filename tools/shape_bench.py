@@ -1,4 +1,6 @@
-"""Throughput of the DMC step and VMC step for several N (development tool)."""
+"""Throughput of the DMC step and VMC step for several N, on ensembles
+equilibrated by --equil VMC steps (development tool).
+usage: shape_bench.py [--equil E] [N ...]"""
 import os, sys, time
 from math import pi
 import numpy as np
@@ -6,7 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
 from phd_qmclib_amd.mrbp_qmc import Spec
 
-for n, W in [(16, 1 << 20), (24, 1 << 19), (64, 1 << 18), (100, 1 << 17), (128, 1 << 17), (256, 1 << 15), (512, 1 << 13)]:
+args = sys.argv[1:]
+equil = 200
+if '--equil' in args:
+    i = args.index('--equil')
+    equil = int(args[i + 1])
+    del args[i:i + 2]
+sizes = [int(a) for a in args] or [16, 24, 37, 48, 63, 64, 100, 128, 256, 512]
+for n in sizes:
+    W = max(1 << 13, min(1 << 20, (1 << 24) // n // 64 * 64))
     spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
                 boson_number=n, supercell_size=n, tbf_contact_cutoff=0.25 * n)
     eng = ModelEngine(spec.cfc_spec, device=0)
@@ -14,7 +24,7 @@ for n, W in [(16, 1 << 20), (24, 1 << 19), (64, 1 << 18), (100, 1 << 17), (128, 
     pos = n * rng.random_sample((W, n))
     v = VmcEnsemble(eng, W, 0.125, rng_seed=1)
     v.set_state(pos)
-    v.run_block(4, sums=False); eng.sync()
+    v.run_block(equil, sums=False); eng.sync()
     eng.timer_start(); v.run_block(8, sums=False); ms = eng.timer_stop()
     vr = W * 8 / (ms * 1e-3)
     maxw = ((W * 512 // 480) + 255) // 256 * 256
