@@ -173,6 +173,11 @@ int qmc_engine_profile_end(qmc_engine *eng, int64_t *launches,
 int qmc_engine_section_profile(qmc_engine *eng, uint64_t *cycles,
                                uint64_t *visits, int32_t nsec, int32_t reset);
 const char *qmc_section_name(int32_t section);
+/* Diagnostic: a library built with -DQMC_CUTS ends every wavefront of the walker
+ * kernels at the section mark selected here (-1: never); hardware counters of
+ * runs cut at successive marks give per-section executed instructions.  The
+ * shipped library returns an error. */
+int qmc_engine_section_cut(qmc_engine *eng, int32_t section);
 
 /* Stands in for model.core_funcs.{wf_abs_log, energy, drift,
  * ith_energy_and_drift} (qmc_base/jastrow/model.py:298-366, 476-564, 756-773,

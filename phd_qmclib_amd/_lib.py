@@ -85,6 +85,7 @@ SIGNATURES = {
                                              C.POINTER(C.c_uint64), C.c_int32,
                                              C.c_int32]),
     'qmc_section_name': (C.c_char_p, [C.c_int32]),
+    'qmc_engine_section_cut': (C.c_int, [_vp, C.c_int32]),
     'qmc_engine_sync': (C.c_int, [_vp]),
     'qmc_engine_timer_start': (C.c_int, [_vp]),
     'qmc_engine_timer_stop': (C.c_int, [_vp, C.POINTER(C.c_float)]),

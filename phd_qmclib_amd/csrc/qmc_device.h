@@ -42,11 +42,21 @@
 // wavefront's previous mark to the section that ends there -- the share of a
 // wavefront's lifetime each section takes, measured while the kernel runs
 // (qmc_engine_section_profile).
+// -DQMC_CUTS (tools/section_counts.py, diagnostic): a wavefront ENDS at the
+// mark whose id the host selected (qmc_engine_section_cut); instruction counters
+// of runs cut at successive marks differ by what a section executes.
 #define QMC_NSEC 32
 #define QMC_SEC_COPIES 1024
 #if defined(QMC_TIMING)
 #define QMC_SECTION(name) qmc_stamp(m, qmc_sec_id(name))
 #define QMC_SECTION_PHASE(off) qmc_stamp_phase(off)
+#elif defined(QMC_CUTS)
+#define QMC_SECTION(name)                                                     \
+    do {                                                                      \
+        if (m.sec_cut == qmc_sec_id(name) + QMC_SEC_OFF)                      \
+            __builtin_amdgcn_endpgm();                                        \
+    } while (0)
+#define QMC_SECTION_PHASE(off) do { } while (0)
 #elif defined(QMC_SECTIONS)
 #define QMC_SECTION(name) asm volatile("; SECTION " name)
 #define QMC_SECTION_PHASE(off) do { } while (0)
@@ -129,6 +139,7 @@ struct DevModel {
     double tg_inv_h, tg_h;
     double tg_a1, tg_b1;   // pi/L, -(pi/L) h/2:  angle offset = a dz + b
     double tg_a2, tg_b2;   // k2,   -k2 h/2
+    int sec_cut;           // QMC_CUTS builds: id of the mark where a wave ends
     // QMC_TIMING builds: QMC_SEC_COPIES x ([QMC_NSEC] cycles + [QMC_NSEC]
     // visits) (else null); a workgroup adds into copy blockIdx.x mod
     // QMC_SEC_COPIES (every wavefront adding into ONE set of counters
@@ -1085,159 +1096,6 @@ __device__ __forceinline__ void pair_core1(const PairConstsT<R> &m, R as,
     Yout = Y;
 }
 
-// log|psi|-only pair loop of the one-walker-per-wavefront, one-particle-per-lane
-// shape with the shifted table copy (pair_core1's world): the first pass of the
-// two-pass VMC step.  Same pair arithmetic and the same phases as the rotation
-// of eval_walker (neighbour steps, leading all-short steps, general steps), but
-// written for latency rather than instruction count: a step here is 4-8 vector
-// instructions, so a wavefront that waits for its LDS read in every step and
-// branches four times per step leaves the vector ALU idle even at eight
-// wavefronts per SIMD (measured with the section stamps: this pass took longer
-// than the energy pass, which executes three times the instructions).  The
-// partner's tables are therefore requested one step (general phase) or one
-// two-step chunk (leading phase) ahead, and the leading phase decides two steps
-// with one scalar test.
-//   prodS/expS : product of the short-range factors cos(k2 r - phi) (mantissa,
-//                binary exponent);  prodL/expL: product of |Y| over ALL pairs
-//   ns_wave    : number of short pairs of the walker
-template <typename R>
-__device__ __forceinline__ void logpsi_pairs64(const PairConstsT<R> &pc, R as,
-                                               R ac, const OwnShort1T<R> &o,
-                                               int gl, const R *lS, const R *lC,
-                                               const R *lSU, const R *lCU,
-                                               R &prodS, int &expS, R &prodL,
-                                               int &expL, int &ns_wave)
-{
-    constexpr int G = 64;
-    // partner of rotation step k: entry (G + gl) - k of the doubled tables
-    const R *pS = lS + G + gl, *pC = lC + G + gl;
-    const R *pSU = lSU + G + gl, *pCU = lCU + G + gl;
-    int k = 1;
-    R P1 = 1;                  // factors of the leading steps (all short)
-    int ns = 0;
-    if (pc.sp_ok) {
-        const R osu = pSU[0], ocu = pCU[0];
-        const R b1su = pSU[-1], b1cu = pCU[-1], b2su = pSU[-2], b2cu = pCU[-2];
-        // first chunk of the one-case steps, requested now
-        R n0su = pSU[-3], n0cu = pCU[-3], n1su = pSU[-4], n1cu = pCU[-4];
-        // k = 1, 2: the form that is exact for either order of the neighbours
-        const R Su1 = osu * b1cu - ocu * b1su, Cu1 = ocu * b1cu + osu * b1su;
-        const R Su2 = osu * b2cu - ocu * b2su, Cu2 = ocu * b2cu + osu * b2su;
-        // |k2 D'| < pi: |D'| < rm iff cos(k2 D') > cos(k2 rm)
-        const bool ok1 = __builtin_amdgcn_ballot_w64(Cu1 > pc.sp_cos) == ~0ull;
-        const bool ok2 = __builtin_amdgcn_ballot_w64(Cu2 > pc.sp_cos) == ~0ull;
-        const R Y1 = q_fma(q_abs(Su1), pc.sphi, Cu1 * pc.cphi);
-        const R Y2 = q_fma(q_abs(Su2), pc.sphi, Cu2 * pc.cphi);
-        bool lead = false;
-        if (ok1 && ok2) { P1 = Y1 * Y2; ns = 2 * G; k = 3; lead = true; }
-        else if (ok1) { P1 = Y1; ns = G; k = 2; }
-        // k = 3 ..: the single case of the shifted tables, two steps per test
-        while (lead && k + 1 < G / 2) {
-            const R b0su = n0su, b0cu = n0cu, b1su_ = n1su, b1cu_ = n1cu;
-            // (k + 3 <= G/2 + 1: inside the doubled tables for every lane)
-            n0su = pSU[-(k + 2)]; n0cu = pCU[-(k + 2)];
-            n1su = pSU[-(k + 3)]; n1cu = pCU[-(k + 3)];
-            const R X0 = o.ks0 * b0cu - o.kc0 * b0su;
-            const R Y0 = o.c0 * b0cu + o.s0 * b0su;
-            const R X1 = o.ks0 * b1cu_ - o.kc0 * b1su_;
-            const R Y1_ = o.c0 * b1cu_ + o.s0 * b1su_;
-            const unsigned long long f0 =
-                __builtin_amdgcn_ballot_w64(X0 > pc.sp_xlo) &
-                __builtin_amdgcn_ballot_w64(X0 < pc.sp_xhi) &
-                __builtin_amdgcn_ballot_w64(Y0 > (R)0);
-            const unsigned long long f1 =
-                __builtin_amdgcn_ballot_w64(X1 > pc.sp_xlo) &
-                __builtin_amdgcn_ballot_w64(X1 < pc.sp_xhi) &
-                __builtin_amdgcn_ballot_w64(Y1_ > (R)0);
-            if ((f0 & f1) == ~0ull) {
-                P1 *= Y0 * Y1_;
-                ns += 2 * G;
-                k += 2;
-                // (factors >= cos(phi): eight steps stay inside the range of
-                // a float as well)
-                if (sizeof(R) == 4 && (k & 7) == 3) {
-                    int e = 0;
-                    q_fold(P1, e);
-                    expS += e; expL += e;
-                }
-            } else {
-                if (f0 == ~0ull) { P1 *= Y0; ns += G; k += 1; }
-                lead = false;
-            }
-        }
-    }
-    // ---- general steps k .. G/2: classified pair by pair ----
-    R PL = 1, PS = 1;
-    int eL = 0, eS = 0;
-    const R own_su = pSU[0], own_cu = pCU[0];
-    R bs = pS[-k], bc = pC[-k];
-    // one step against the partner tables (cs, cc) [+ (su, cu) on demand];
-    // `mine`: this lane tallies the pair
-#define QMC_WF_STEP(mine)                                                     \
-    {                                                                         \
-        const R S = as * cc - ac * cs;        /* sin(pi (z_a - z_b') / L) */   \
-        const bool sh = (mine) & (q_abs(S) < pc.sin_rm); /* min-image r < rm */\
-        ns += __popcll(__builtin_amdgcn_ballot_w64(sh));                      \
-        R Y = S;                                                              \
-        if (sh) {                                                             \
-            const R bsu = pSU[-k], bcu = pCU[-k];                             \
-            const R Xc = ac * cc + as * cs;   /* cos(...): its sign only */    \
-            if ((S > (R)0) & (Xc > (R)0)) {                                   \
-                /* 0 < D' < L/2: Y = cos(k2 D' - phi) */                      \
-                asm volatile("");                                             \
-                Y = o.c0 * bcu + o.s0 * bsu;                                  \
-            } else {                                                          \
-                asm volatile("");                                             \
-                /* any order of the lanes (pair_core1's generic branch) */    \
-                R su_ = bsu, cu_ = bcu, Sg = S, Xg = Xc;                      \
-                if (gl < k) {                                                 \
-                    const R s2 = su_ * pc.cth + cu_ * pc.sth_signed;          \
-                    const R c2 = cu_ * pc.cth - su_ * pc.sth_signed;          \
-                    su_ = s2; cu_ = c2; Sg = -S; Xg = -Xc;                    \
-                }                                                             \
-                R Su = own_su * cu_ - own_cu * su_; /* sin(k2 (z_a - z_b)) */  \
-                R Cu = own_cu * cu_ + own_su * su_;                           \
-                if (Xg < (R)0) {                                              \
-                    const R t = (Sg < (R)0) ? -pc.sth_signed : pc.sth_signed; \
-                    const R ns_ = Su * pc.cth - Cu * t;                       \
-                    const R nc_ = Cu * pc.cth + Su * t;                       \
-                    Su = ns_; Cu = nc_;                                       \
-                }                                                             \
-                Y = q_fma(q_abs(Su), pc.sphi, Cu * pc.cphi);                  \
-            }                                                                 \
-            PS *= Y;                                                          \
-        }                                                                     \
-        if (mine) PL *= Y;                                                    \
-    }
-    for (; k < G / 2; ++k) {
-        const R cs = bs, cc = bc;
-        bs = pS[-(k + 1)]; bc = pC[-(k + 1)];    // the next step's, already
-        QMC_WF_STEP(true)
-        if ((k & (sizeof(R) == 4 ? 7 : 15)) == 0) {
-            asm volatile("");
-            q_fold(PS, eS);
-            q_fold(PL, eL);
-        }
-    }
-    {
-        // the final half step visits every pair from both sides: the lower
-        // half of the lanes tallies
-        const R cs = bs, cc = bc;
-        const bool lower = gl < G / 2;
-        QMC_WF_STEP(lower)
-    }
-#undef QMC_WF_STEP
-    // the leading steps belong to both products
-    int e1 = 0;
-    q_fold(P1, e1);
-    PS *= P1; PL *= P1;
-    q_fold(PS, eS);
-    q_fold(PL, eL);
-    prodS = PS; expS += eS + e1;
-    prodL = PL; expL += eL + e1;
-    ns_wave += ns;
-}
-
 // LDS table of one lane group: 4 (5 with ZCLASS: + positions) arrays of
 // DUP*G*P doubles.  For P = 1 every entry is stored twice (lane g at g and
 // G + g) so a rotated read (g - k) never needs a modulo; for P >= 2 the copy
@@ -1255,9 +1113,6 @@ __device__ __forceinline__ void logpsi_pairs64(const PairConstsT<R> &pc, R as,
 #endif
 #ifndef QMC_TWOCASE
 #define QMC_TWOCASE 1
-#endif
-#ifndef QMC_WF_LOOP
-#define QMC_WF_LOOP 1
 #endif
 
 // Tile-sweep knobs of the N = 512 shape (BASELINE.json configs[4]: "LDS
@@ -1304,6 +1159,8 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
 {
     constexpr int DUP = GroupLds<G, P, ZCLASS>::DUP;
     constexpr int ROW = GroupLds<G, P, ZCLASS>::ROW;
+    // (section ids of the energy pass after an accepted VMC move: second half)
+    [[maybe_unused]] constexpr int QMC_SEC_OFF = REUSE ? QMC_NSEC / 2 : 0;
     // Own particles are processed PA at a time: with P = 8 the tables of all
     // eight (96 VGPRs) would leave one wave per SIMD, so the rotation runs in
     // two passes of four own particles (tables re-read from LDS).
@@ -1703,14 +1560,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         int k_first = 1;
         constexpr bool LEAD_SHORT = QMC_LEAD_SHORT && ROTCOPY && (G == 64) &&
                                     !PAD && (P == 1);
-        // the log|psi|-only pass has its own loop (logpsi_pairs64)
-        constexpr bool WF_LOOP = QMC_WF_LOOP && LEAD_SHORT && !EN && WF;
-        if constexpr (WF_LOOP) {
-            QMC_SECTION("rotation");
-            logpsi_pairs64<R>(pc, t[0].s, t[0].c, os1[0], gl, lS, lC, lSU, lCU,
-                              prodS, expS, prodL, expL, ns_wave);
-            k_first = G;        // nothing left for the passes below
-        } else if constexpr (LEAD_SHORT) {
+        if constexpr (LEAD_SHORT) {
             if (pc.sp_ok) {
                 R Q1 = 0, P1 = 1;          // tallies of these steps
                 int e1 = 0;
@@ -1788,13 +1638,11 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 }
             }
         }
-        if constexpr (!WF_LOOP) {
-            QMC_SECTION("rotation");
-            QMC_PASS(0)
-            QMC_PASS(1)
-            QMC_PASS(2)
-            QMC_PASS(3)
-        }
+        QMC_SECTION("rotation");
+        QMC_PASS(0)
+        QMC_PASS(1)
+        QMC_PASS(2)
+        QMC_PASS(3)
 #undef QMC_PASS
 #undef QMC_KSTEP
     }

@@ -30,6 +30,27 @@ struct WalkBlock {
     static constexpr int N = (G == 64) ? QMC_BLOCK64 : BLOCK;
 };
 
+// Which walker a workgroup of the one-wavefront-per-workgroup kernels owns.
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD
+// b mod 8) and every XCD has its own L2.  The per-walker scalars (log|psi|,
+// carried energy, block sums; DMC: energy, weight, cloning reference) are 8
+// bytes each, 16 walkers to a 128-byte line: with walker = workgroup index the
+// 16 walkers of a line sit on 8 different XCDs and every L2 fetches and writes
+// back the whole line for its two walkers (measured: 1699 bytes of HBM traffic
+// per VMC chain-step against the algorithmic 1056).  Here the 16 walkers of a
+// line go to ONE XCD: within every run of 128 workgroups, XCD x takes walkers
+// 16 x .. 16 x + 15.  (The launch grid is rounded up to a multiple of 128.)
+#ifndef QMC_XCD_MAP
+#define QMC_XCD_MAP 1
+#endif
+template <int GPB>
+__device__ __forceinline__ long long walker_of_block(unsigned b, int grp)
+{
+    if (QMC_XCD_MAP && GPB == 1)
+        return ((long long)(b >> 7) << 7) + ((b & 7u) << 4) + ((b & 127u) >> 3);
+    return (long long)b * GPB + grp;
+}
+
 // LDS doubles per lane group of the stepping kernels (vmc_step, dmc_evolve):
 // the sorted-row path of the exact N = 128 shape keeps the positions as well,
 // 5 rows of 192 entries (qmc_sorted64.h: sorted_particle_setup)
@@ -106,13 +127,15 @@ evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
     // model constants live in device memory: scalar loads on demand keep the
     // SGPR file free for the hot loop (by-value they overflow it)
     const DevModel &m = *mp;
+    [[maybe_unused]] constexpr int QMC_SEC_OFF = 0;
     QMC_SECTION("top");
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;            // groups per block
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
-    const long long w = (long long)blockIdx.x * GPB + grp;
+    const long long w = walker_of_block<GPB>(blockIdx.x, grp);
     const bool active = w < a.nconf;
+    if (GPB == 1 && !active) return;      // (no one else in the workgroup)
     const long long wr = active ? w : 0;
     double z[P], F[P], ei[P], E, wf;
 #pragma unroll
@@ -151,13 +174,15 @@ prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
     // model constants live in device memory: scalar loads on demand keep the
     // SGPR file free for the hot loop (by-value they overflow it)
     const DevModel &m = *mp;
+    [[maybe_unused]] constexpr int QMC_SEC_OFF = 0;
     QMC_SECTION("top");
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * GroupLds<G, P, ZC>::DOUBLES;
-    const long long w = (long long)blockIdx.x * GPB + grp;
+    const long long w = walker_of_block<GPB>(blockIdx.x, grp);
     const bool active = w < a.nconf;
+    if (GPB == 1 && !active) return;      // (no one else in the workgroup)
     const long long wr = active ? w : 0;
     double z[P], F[P], ei[P], E, wf;
 #pragma unroll
@@ -212,13 +237,15 @@ __global__ void __launch_bounds__(WalkBlock<G>::N QMC_LB_WAVES_VMC)
 vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
 {
     const DevModel &m = *mp;
+    [[maybe_unused]] constexpr int QMC_SEC_OFF = 0;
     QMC_SECTION("top");
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
-    const long long w = (long long)blockIdx.x * GPB + grp;
+    const long long w = walker_of_block<GPB>(blockIdx.x, grp);
     const bool active = w < a.W;
+    if (GPB == 1 && !active) return;      // (no one else in the workgroup)
     const long long wr = active ? w : 0;
     const int n = m.n;
     const unsigned int slot = a.chain0 + (unsigned int)wr;
@@ -461,14 +488,15 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     // model constants live in device memory: scalar loads on demand keep the
     // SGPR file free for the hot loop (by-value they overflow it)
     const DevModel &m = *mp;
+    [[maybe_unused]] constexpr int QMC_SEC_OFF = 0;
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
-    const long long s = (long long)blockIdx.x * GPB + grp;
+    const long long s = walker_of_block<GPB>(blockIdx.x, grp);
     const long long nw = a.ctl->nw;
     // whole block beyond the population: nothing to do
-    if ((long long)blockIdx.x * GPB >= nw) return;
+    if ((GPB == 1 ? s : (long long)blockIdx.x * GPB) >= nw) return;
     QMC_SECTION("top");
     const bool active = s < nw;
     const long long sr = active ? s : 0;

@@ -278,6 +278,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     const bool live = !PAD || gl < nl;
     const unsigned long long live_mask =
         PAD ? __builtin_amdgcn_ballot_w64(live) : ~0ull;
+    [[maybe_unused]] constexpr int QMC_SEC_OFF = REUSE ? QMC_NSEC / 2 : 0;
     QMC_SECTION("tables+onebody");
     Own64<R> o;
     SortedOneBody ob;

@@ -174,7 +174,10 @@ template <int G>
 static unsigned grid_for(long long nwalkers)
 {
     const long long gpb = WalkBlock<G>::N / G;
-    return (unsigned)((nwalkers + gpb - 1) / gpb);
+    long long blocks = (nwalkers + gpb - 1) / gpb;
+    // (one wavefront per workgroup: walker_of_block permutes runs of 128)
+    if (QMC_XCD_MAP && gpb == 1) blocks = (blocks + 127) / 128 * 128;
+    return (unsigned)blocks;
 }
 
 // The float pair loop exists for the one-wavefront-per-walker shapes with
@@ -326,6 +329,7 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     double phi = p.param_k2 * p.param_r_off;
     d.cphi = cos(phi);
     d.sphi = sin(phi);
+    d.sec_cut = -1;
     d.am_cphi = fabs(p.param_am) * d.cphi;
     d.am_sphi = fabs(p.param_am) * d.sphi;
     d.m_k2cphi = -d.k2 * d.cphi;
@@ -883,6 +887,28 @@ extern "C" int qmc_engine_section_profile(qmc_engine *e, uint64_t *cycles,
     (void)cycles; (void)visits; (void)nsec; (void)reset;
     return fail("qmc_engine_section_profile: this library was built without "
                 "-DQMC_TIMING (see tools/section_times.py)");
+#endif
+}
+
+// Diagnostic libraries built with -DQMC_CUTS (tools/section_counts.py): from
+// now on every wavefront of the walker kernels ends when it reaches section
+// mark `section` (-1: never).  The results of such launches are meaningless;
+// hardware counters of runs cut at successive marks give the instructions each
+// section executes.  The shipped library has no cut tests in its kernels.
+extern "C" int qmc_engine_section_cut(qmc_engine *e, int32_t section)
+{
+    if (!e) return fail("qmc_engine_section_cut: null engine");
+#if defined(QMC_CUTS)
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->dm.sec_cut = section;
+    HIP_TRY(hipMemcpy(e->dm_dev, &e->dm, sizeof(DevModel),
+                      hipMemcpyHostToDevice));
+    return 0;
+#else
+    (void)section;
+    return fail("qmc_engine_section_cut: this library was built without "
+                "-DQMC_CUTS (see tools/section_counts.py)");
 #endif
 }
 

@@ -189,6 +189,15 @@ class ModelEngine:
                 out[name] = (int(cyc[i]), int(vis[i]))
         return out
 
+    def section_cut(self, section: int):
+        """Diagnostic libraries only (built with -DQMC_CUTS,
+        tools/section_counts.py): end every wavefront of the walker kernels at
+        section mark `section` (-1: never).  Raises with the shipped library."""
+        check(self._lib.qmc_engine_section_cut(self._h, int(section)))
+
+    def section_names(self):
+        return [self._lib.qmc_section_name(i).decode() for i in range(16)]
+
     def close(self):
         if getattr(self, '_h', None):
             self._lib.qmc_engine_destroy(self._h)
