@@ -26,7 +26,7 @@ def parse(path):
 
 
 res = {'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* in '
-                 'separate passes (tools/profile.sh), profiles/r02_*_pmc_summary.txt',
+                 'separate passes (tools/profile.sh), profiles/r03_*_pmc_summary.txt',
        'correction': 'read bytes = 2 x FETCH_SIZE x 1024 (gfx950 half-count of '
                      'coalesced reads), write bytes = WRITE_SIZE x 1024'}
 for arg in sys.argv[1:]:
