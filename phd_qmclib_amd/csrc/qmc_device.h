@@ -343,8 +343,31 @@ __device__ __forceinline__ double wave_partial_mfma(double v)
     return (d[0] + d[1]) + (d[2] + d[3]);
 }
 
+// One sum over the wavefront through the 4x4x4 form (four independent 4x4
+// blocks; 16 cycles an instruction against 64 for 16x16x4, profiles/
+// r02_ubench3_mfma_overlap.txt).  Lane layout, probed on the chip
+// (tools/mfma4_layout.hip): block b = (lane / 4) % 4; A[i][k] sits in lane
+// i + 4 b + 16 k and D[i][j] in lane j + 4 b + 16 i.  Against B = ones the first
+// product leaves, in row i of the wavefront, the sum over the four rows of
+// the lanes i + 4 b; fed back as A the second leaves the total of the block's
+// 16 lanes {i + 4 b + 16 k} in all of them; two rotations inside the rows of
+// 16 (by 4 and by 8 lanes: DPP, no LDS) add the four blocks.
+#ifndef QMC_MFMA4_SUM
+#define QMC_MFMA4_SUM 1
+#endif
+template <int N> __device__ __forceinline__ double row_ror_f64(double v);
+__device__ __forceinline__ double wave_sum_mfma4(double v)
+{
+    const double r = __builtin_amdgcn_mfma_f64_4x4x4f64(v, 1.0, 0.0, 0, 0, 0);
+    double t = __builtin_amdgcn_mfma_f64_4x4x4f64(r, 1.0, 0.0, 0, 0, 0);
+    t += row_ror_f64<4>(t);
+    t += row_ror_f64<8>(t);
+    return t;
+}
+
 __device__ __forceinline__ double wave_sum_mfma(double v)
 {
+    if (QMC_MFMA4_SUM) return wave_sum_mfma4(v);
     const qmc_v4d zero = {0.0, 0.0, 0.0, 0.0};
     const qmc_v4d t = __builtin_amdgcn_mfma_f64_16x16x4f64(
         wave_partial_mfma(v), 1.0, zero, 0, 0, 0);
@@ -354,6 +377,11 @@ __device__ __forceinline__ double wave_sum_mfma(double v)
 __device__ __forceinline__ void wave_sum2_mfma(double a, double b, double &sa,
                                                double &sb)
 {
+    if (QMC_MFMA4_SUM) {
+        sa = wave_sum_mfma4(a);
+        sb = wave_sum_mfma4(b);
+        return;
+    }
     const qmc_v4d zero = {0.0, 0.0, 0.0, 0.0};
     const double pa = wave_partial_mfma(a), pb = wave_partial_mfma(b);
     const qmc_v4d t = __builtin_amdgcn_mfma_f64_16x16x4f64(
