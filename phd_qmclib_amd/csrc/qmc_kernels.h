@@ -56,9 +56,13 @@ __device__ __forceinline__ long long walker_of_block(unsigned b, int grp)
 // 5 rows of 192 entries (qmc_sorted64.h: sorted_particle_setup)
 template <int G, int P, bool PAD, bool ZC>
 struct StepLds {
+    // (+ one row of partner sums, qmc_sorted64.h: QMC_T_LDS)
     static constexpr int DOUBLES =
         (QMC_SORTED128 && G == 64 && P == 2 && !ZC)
-            ? 5 * SortedRows<128>::ROW : GroupLds<G, P, ZC>::DOUBLES;
+            ? 5 * SortedRows<128>::ROW
+            : (QMC_SORTED64 && G == 64 && P == 1 && !ZC)
+                  ? (QMC_T_LDS ? 6 : 5) * SortedRows<64>::ROW
+                  : GroupLds<G, P, ZC>::DOUBLES;
 };
 
 // a wave-uniform 64-bit value as the compiler can see it (scalar registers)

@@ -37,6 +37,16 @@
 #ifndef QMC_LDS_AHEAD
 #define QMC_LDS_AHEAD 0
 #endif
+// The partner's share of a pair's drift: added into an LDS row at the partner's
+// table index with ds_add_f64 (1), or carried in a travelling register that
+// rotates one lane per step (0: a subtraction and two DPP moves per step).
+// Measured twice now (round 2 on the general path, round 3 here): the atomics
+// remove 3 vector instructions per step of the energy pass and are SLOWER --
+// VMC 1.882 against 1.829 ms, DMC 0.526 against 0.515 (profiles/
+// r03_ab_variants.txt): ds_add_f64 occupies the LDS pipe for 32 cycles.
+#ifndef QMC_T_LDS
+#define QMC_T_LDS 0
+#endif
 
 // lane i takes the value of lane i - 1 (lane 0 keeps its own)
 __device__ __forceinline__ double wave_shr1_f64(double v)
@@ -271,6 +281,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     constexpr int G = 64, H = SortedRows<G>::H, ROW = SortedRows<G>::ROW;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
+    // sixth row (double whatever R is): the sums the partners collect
+    constexpr bool T_LDS = QMC_T_LDS && EN;
+    double *lA = lds + 5 * ROW;
     const int nl = PAD ? m.n : G;            // lanes in use = particles
     const int K = nl / 2;                    // rotation steps
     const bool half_last = !PAD || (nl & 1) == 0;   // step K is a half step
@@ -283,7 +296,15 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     Own64<R> o;
     SortedOneBody ob;
     sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob, nl);
-    if (!REUSE) {
+    // (where the shares of this lane's particle arrive: its own index from the
+    // lanes above it, the index one period below from the lanes that reach it
+    // around the end of the row)
+    const int a_lo = H + gl - nl;
+    if (T_LDS && live) {
+        lA[H + gl] = 0.0;
+        if (a_lo >= 1) lA[a_lo] = 0.0;
+    }
+    if (!REUSE || T_LDS) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -297,6 +318,8 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     // partner of rotation step k: entry (H + gl) - k
     const R *pS = lS + H + gl, *pC = lC + H + gl, *pSU = lSU + H + gl,
             *pCU = lCU + H + gl, *pZ = lZ + H + gl;
+    typedef __attribute__((address_space(3))) double *lds_dptr;
+    const lds_dptr pA = (lds_dptr)(lA + H + gl);
     // the lane below in the ring of the lanes in use (travelling sums)
     int ring_src = 0;
     if (PAD) ring_src = (live ? (gl == 0 ? nl - 1 : gl - 1) : gl) << 2;
@@ -327,12 +350,18 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     R X = 0;                                                                  \
     if (EN) X = o.ks0 * (bcu) - o.kc0 * (bsu);                                \
     if (WF) PS *= Y;
-    // the quotient's way into the sums of a step that is not the last
-#define QMC_S64_ADD_Q(q)                                                      \
+    // the quotient's way into the sums of step kk (not the last step)
+#define QMC_S64_ADD_Q(q, kk)                                                  \
     {                                                                         \
         Fr += (q);                                                            \
-        T -= (q);                                                             \
-        T = (R)QMC_S64_ROR(T);                                                \
+        if (T_LDS) {                                                          \
+            if (live)                                                         \
+                (void)__builtin_amdgcn_ds_atomic_fadd_f64(pA - (kk),          \
+                                                          -(double)(q));      \
+        } else {                                                              \
+            T -= (q);                                                         \
+            T = (R)QMC_S64_ROR(T);                                            \
+        }                                                                     \
     }
     // every lane in use says yes
 #define QMC_S64_ALL(cond)                                                     \
@@ -351,7 +380,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
             if (!QMC_S64_ALL(bz > o.zt)) {
                 if (EN) {
                     const R q = pair_div(Xa, Ya);
-                    QMC_S64_ADD_Q(q)
+                    QMC_S64_ADD_Q(q, k - 1)
                     Qs = q_fma(q, q, Qs);
                 }
                 break;
@@ -365,8 +394,8 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                 // Yb -- measured no faster, 1 % slower in the VMC step: the
                 // reciprocal does not hold up the multiply-add pipe)
                 const R qa = pair_div(Xa, Ya), qb = pair_div(Xb, Yb);
-                QMC_S64_ADD_Q(qa)
-                QMC_S64_ADD_Q(qb)
+                QMC_S64_ADD_Q(qa, k - 2)
+                QMC_S64_ADD_Q(qb, k - 1)
                 Qs = q_fma(qa, qa, Qs);
                 Qs = q_fma(qb, qb, Qs);
             }
@@ -420,8 +449,8 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
             k += 2;
             if (EN) {
                 const R qa = pair_div(Xa, Ya), qb = pair_div(Xb, Yb);
-                QMC_S64_ADD_Q(qa)
-                QMC_S64_ADD_Q(qb)
+                QMC_S64_ADD_Q(qa, k - 2)
+                QMC_S64_ADD_Q(qb, k - 1)
                 QMC_S64_TALLY(qa, sha, minea)
                 QMC_S64_TALLY(qb, shb, mineb)
             }
@@ -436,7 +465,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
             QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
             if (EN) {
                 const R q = pair_div(Xa, Ya);
-                QMC_S64_ADD_Q(q)
+                QMC_S64_ADD_Q(q, k)
                 QMC_S64_TALLY(q, sha, minea)
             }
             ++k;
@@ -459,7 +488,14 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
 #undef QMC_S64_TALLY
 #undef QMC_S64_ADD_Q
 #undef QMC_S64_ALL
-    if (EN) {
+    if (T_LDS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double t = lA[H + gl];
+        if (a_lo >= 1) t += lA[a_lo];
+        Fr += (R)t;
+    } else if (EN) {
         // after kfull rotations lane l holds the sum of particle l - kfull - 1
         if (PAD) {
             int src = gl + kfull + 1;
