@@ -255,3 +255,52 @@ def test_rccl_all_reduce_is_ordered_with_the_engine_stream():
             a.close(); b.close(); eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_on_one_gpu_real_engine():
+    """`bench.py --gpus 2` with the HIP engine on both ranks (sharing this GPU)
+    and gloo as transport (tests/_bench_gpu_gloo.py): the multi-rank logic of the
+    headline run -- unequal start, split step with the global (E_t, W_t), forced
+    rebalances moving real walker records between two processes, conservation,
+    bit-identical E_ref on both ranks, phases -- on the product kernels.  What
+    it cannot cover is RCCL itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
+                        'MASTER_PORT')}
+    env['QMC_BENCH_BACKEND'] = 'tests._bench_gpu_gloo'
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+         '--steps', '12', '--warmup', '4', '--equil', '100',
+         '--c4-bosons', '128', '--c4-walkers', '16384', '--chains', '4096',
+         '--rebalance-every', '4', '--launch-timeout', '500', '--no-checks'],
+        env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong'
+    assert out['backend'].startswith('hip + gloo')
+    ex = out['extra']
+    wu, tm = ex['rebalance_checks']['warmup'], ex['rebalance_checks']['timed']
+    # 8192 +- 3 %: 245 walkers moved in the warm-up (sent + received: 490)
+    assert max(wu['counts_before']) - min(wu['counts_before']) > 400
+    assert max(wu['counts_after']) - min(wu['counts_after']) <= 1
+    assert sum(wu['counts_before']) == sum(wu['counts_after'])
+    assert sum(tm['counts_before']) == sum(tm['counts_after'])
+    assert ex['walkers_moved_warmup_all_ranks'] >= 400
+    assert ex['walkers_moved_all_ranks'] > 0
+    assert ex['ref_energy_identical_on_all_ranks'] is True
+    # (a short run from chains equilibrated for 100 steps only: the result
+    # windows of the real benchmark are switched off, a sanity window here)
+    assert 14.5 < ex['dmc_energy_per_particle'] < 16.5
+    assert 0.9 * 16384 < ex['mean_walkers'] < 1.1 * 16384
+    assert ex['phases']['evolve_kernel_ms_per_step'] > 0
+    # the weak-scaled VMC extra ran on both ranks as well
+    assert ex['vmc_weak']['value'] > 0
+    assert 15.0 < ex['vmc_weak']['energy_per_particle'] < 16.5
