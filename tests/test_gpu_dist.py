@@ -304,3 +304,36 @@ def test_bench_two_ranks_on_one_gpu_real_engine():
     # the weak-scaled VMC extra ran on both ranks as well
     assert ex['vmc_weak']['value'] > 0
     assert 15.0 < ex['vmc_weak']['energy_per_particle'] < 16.5
+
+
+def test_distributed_vmc_reduces_block_sums_on_the_device():
+    """`DistributedVmc.run_block` on a GPU ensemble sums the per-chain block sums
+    where they are (it used to download 24 bytes per chain); the
+    statistics must be those of the per-chain arrays of an identical run."""
+    import types
+    from phd_qmclib_amd.dist import DistributedVmc
+    from phd_qmclib_amd.engine import ModelEngine, VmcEnsemble
+    n, W = 64, 3000
+    eng = ModelEngine(box(n).cfc_spec)
+    pos = n * np.random.RandomState(12).random_sample((W, n))
+
+    def make(first_chain):
+        v = VmcEnsemble(eng, W, 0.125, rng_seed=8, chain0=first_chain)
+        v.set_state(pos)
+        return types.SimpleNamespace(ensemble=v)
+
+    dv = DistributedVmc(make, W, device='cuda')
+    ref = make(0).ensemble
+    for _ in range(2):
+        got = dv.run_block(24)
+        out = ref.run_block(24)
+        tot = float(W * 24)
+        assert got['num_samples'] == tot
+        assert got['energy_mean'] == pytest.approx(out['sum_energy'].sum() / tot,
+                                                   rel=1e-12)
+        assert got['energy2_mean'] == pytest.approx(
+            out['sum_energy2'].sum() / tot, rel=1e-12)
+        assert got['accept_rate'] == out['num_accepted'].sum() / tot
+    dv.sampling.ensemble.close()
+    ref.close()
+    eng.close()
