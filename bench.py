@@ -19,7 +19,12 @@ What a "step" is and which workload is the headline:
   (`dist.DistributedDmc`): per time step every rank branches and propagates
   its walkers, a 16-byte RCCL all-reduce gives the global (E_t, W_t) for the
   E_ref feedback, and the ranks level their populations with point-to-point
-  walker transfers.  Total work is fixed as N grows: `"scaling": "strong"`.
+  walker transfers.  The ranks start +-3 % off their share and the population
+  is levelled by FORCED rebalances (one in the warm-up, one in the timed
+  region), so that the run moves real walker records over RCCL; walker
+  conservation and bit-identical E_ref on all ranks are asserted and
+  `extra.phases` times the all-reduce, the host enqueue, the rebalances and the
+  evolve kernel.  Total work is fixed as N grows: `"scaling": "strong"`.
   `extra.vmc_weak` is the VMC workload at 2^20 chains per GPU.
 
 The ensembles start from EQUILIBRATED configurations (>= 300 untimed
@@ -31,7 +36,10 @@ duration, measured with HIP events on the stream it is launched on; the path
 is fp64-VALU bound, so `extra.valu` gives the pair-evaluation rate as well.
 `cpu_baseline` (N = 1, rank 0) times the CPU oracle -- the C restatement of
 the reference algorithm, OpenMP over chains, rebuilt here with -O3
--march=native -- on a bounded sample of the same workload.
+-march=native -- on bounded samples of the same workload: on every core of the
+affinity mask and on 16 threads (`runs`; `value` is the better), and on
+BASELINE configs[0] (`c1`).  `"backend"` names the engine that produced the
+line ("hip"; the CPU stand-ins of tests/ say so).
 """
 import argparse
 import json
