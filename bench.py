@@ -27,6 +27,16 @@ What a "step" is and which workload is the headline:
   evolve kernel.  Total work is fixed as N grows: `"scaling": "strong"`.
   `extra.vmc_weak` is the VMC workload at 2^20 chains per GPU.
 
+Both scaling curves from ONE run at each N: every line, at every --gpus,
+carries `extra.curves = {"vmc_n64_weak": <walker-steps/s>, "dmc_n128_strong":
+<walker-steps/s>}` under the same keys -- the two workloads are never mixed in
+one curve, whatever `value` is at that N -- and `extra.strong_scaling` /
+`extra.weak_scaling` = {ref_1gpu, speedup, efficiency}.  At N > 1 the 1-GPU
+reference points are measured IN THE SAME RUN on rank 0's GPU (the full
+population of configs[3] / one rank's VMC share, through the same code, while
+the other ranks wait at a barrier), so that an efficiency never stitches two
+boxes together; at N = 1 they are the run itself.
+
 The ensembles start from EQUILIBRATED configurations (>= 300 untimed
 Metropolis steps, which also lets the clock settle) and the result windows
 (energy per particle, acceptance) are asserted in here.  Inputs are resident in
@@ -95,6 +105,10 @@ def parse_args(argv=None):
                     help='skip the sharded-DMC workload at --gpus 1')
     ap.add_argument('--no-vmc-extra', action='store_true',
                     help='skip the weak-scaled VMC extra at --gpus > 1')
+    ap.add_argument('--no-scaling-ref', action='store_true',
+                    help='--gpus > 1: skip the same-run 1-GPU reference points '
+                         '(rank 0 alone: the whole DMC population, one VMC '
+                         'share) behind extra.strong_scaling / weak_scaling')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-checks', action='store_true',
                     help='do not assert the energy / acceptance windows '
@@ -250,11 +264,12 @@ class HipBackend:
         return v
 
     def sharded_population(self, n, start, cap, global_target, rank, world,
-                           equil, rebalance_every):
+                           equil, rebalance_every, solo=False):
         """This rank's share of ONE DMC population (external reduce), `start`
         walkers to begin with, and its DistributedDmc driver; the walkers
         start from equilibrated VMC configurations, reused cyclically when
-        there are fewer chains."""
+        there are fewer chains.  `solo`: the whole population on this rank,
+        no collective whatever the process group (the 1-GPU reference)."""
         import torch.distributed as dist
         from phd_qmclib_amd.dist import DistributedDmc
         from phd_qmclib_amd.engine import DmcEnsemble
@@ -275,7 +290,7 @@ class HipBackend:
                              replicate=True)
         v.close()
         dd = DistributedDmc(d, n, self.device,
-                            rebalance_every=rebalance_every)
+                            rebalance_every=rebalance_every, solo=solo)
         return d, dd, eng, chains
 
 
@@ -297,14 +312,41 @@ def check_window(what, value, window, args):
                          f'report a throughput for a wrong result')
 
 
-def load_traffic(n):
-    """Measured HBM bytes / VALU instructions per unit (rocprofv3 PMC passes
-    of tools/profile.sh, committed under profiles/)."""
+def loaded_kernel_hash():
+    """`qmc_source_hash()` of the library this process runs (None for the CPU
+    stand-ins of tests/, which load no kernels)."""
     try:
-        with open(TRAFFIC_JSON) as fp:
-            return json.load(fp).get(f'N{n}', {})
+        from phd_qmclib_amd import _lib
+        return _lib.source_hash()
+    except Exception:
+        return None
+
+
+def load_traffic(n, kernel, path=None, loaded=None):
+    """Measured HBM bytes / VALU instructions per unit of `kernel`
+    ('vmc_step_kernel' / 'dmc_evolve_kernel') at N = n from the committed
+    rocprofv3 PMC passes (tools/profile.sh -> tools/make_traffic.py ->
+    profiles/traffic.json) -- IF they were taken on the kernels this process
+    runs: the file records `qmc_source_hash()` of the measured library, and a
+    figure whose hash differs from the loaded library's is stale and not
+    reported.  -> (dict of figures without the kernel prefix, note or None)."""
+    path = TRAFFIC_JSON if path is None else path
+    try:
+        with open(path) as fp:
+            ent = json.load(fp).get(f'N{n}', {})
     except (OSError, ValueError):
-        return {}
+        return {}, f'no traffic record ({os.path.basename(path)} unreadable)'
+    pre = kernel + '_'
+    ent = {k[len(pre):]: v for k, v in ent.items() if k.startswith(pre)}
+    if not ent:
+        return {}, f'no traffic record for {kernel} at N={n}'
+    loaded = loaded_kernel_hash() if loaded is None else loaded
+    measured = ent.get('kernel_source_sha')
+    if measured is None or loaded is None or measured != loaded:
+        return {}, (f'profiles/traffic.json was measured on kernels {measured} '
+                    f'but this run loaded {loaded}: stale, not reported -- '
+                    f'rerun tools/profile.sh + tools/make_traffic.py')
+    return ent, None
 
 
 # ---------------------------------------------------------------- VMC leg ---
@@ -368,9 +410,9 @@ def vmc_line(args, m, n, W, world):
     launch_ms = m['kernel_ms'] / m['launches']
     achieved = W * b_vmc / (launch_ms * 1e-3) / 1e9
     pairs = n * (n - 1) // 2
-    tj = load_traffic(n)
-    traffic = tj.get('vmc_step_kernel_bytes_per_chain_step')
-    valu = tj.get('vmc_step_kernel_valu_instr_per_chain_step')
+    tj, traffic_note = load_traffic(n, 'vmc_step_kernel')
+    traffic = tj.get('bytes_per_chain_step')
+    valu = tj.get('valu_instr_per_chain_step')
     return {
         'metric': 'walker-steps/sec',
         'value': value,
@@ -396,6 +438,9 @@ def vmc_line(args, m, n, W, world):
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': None if traffic is None else traffic * W,
+            'traffic_note': traffic_note or
+            'rocprofv3 PMC passes of these kernels (same qmc_source_hash), '
+            'profiles/traffic.json',
             'kernel': 'vmc_step_kernel', 'launch_ms': launch_ms,
             'bytes_per_unit': b_vmc, 'units_per_launch': W,
         },
@@ -455,7 +500,7 @@ def bench_dmc_single(be, args, n, vmc, target):
     }
 
 
-def bench_dmc_sharded(be, args, rank, world, use_pg):
+def bench_dmc_sharded(be, args, rank, world, use_pg, solo=False):
     """configs[3]: ONE population of --c4-walkers (global target) sharded over
     the ranks.  -> dict (identical on every rank).
 
@@ -477,8 +522,10 @@ def bench_dmc_sharded(be, args, rank, world, use_pg):
     if world > 1 and args.start_skew > 0 and rank < world - world % 2:
         delta = int(per_rank * args.start_skew)
         start = per_rank + (delta if rank % 2 == 0 else -delta)
+    kw = dict(solo=True) if solo else {}
     d, dd, eng, chains = be.sharded_population(
-        n, start, cap, target, rank, world, args.equil, args.rebalance_every)
+        n, start, cap, target, rank, world, args.equil, args.rebalance_every,
+        **kw)
 
     def barrier():
         if use_pg:
@@ -619,8 +666,8 @@ def sharded_line(args, s, world):
     """Headline JSON object of the sharded DMC workload."""
     n = args.c4_bosons
     achieved = s.get('hbm_achieved_GBs')
-    tj = load_traffic(n)
-    traffic = tj.get('dmc_evolve_kernel_bytes_per_walker_step')
+    tj, traffic_note = load_traffic(n, 'dmc_evolve_kernel')
+    traffic = tj.get('bytes_per_walker_step')
     return {
         'metric': 'walker-steps/sec',
         'value': s['walker_steps_per_s'],
@@ -648,6 +695,9 @@ def sharded_line(args, s, world):
             'frac': None if achieved is None else achieved / HBM_PEAK_GBS,
             'traffic': None if traffic is None or 'units_per_launch' not in s
             else traffic * s['units_per_launch'],
+            'traffic_note': traffic_note or
+            'rocprofv3 PMC passes of these kernels (same qmc_source_hash), '
+            'profiles/traffic.json',
             'kernel': 'dmc_evolve_kernel',
             'launch_ms': s.get('evolve_kernel_ms'),
             'bytes_per_unit': s['bytes_per_unit'],
@@ -761,6 +811,32 @@ def cpu_baseline(args, spec, n, move_spread):
     return out
 
 
+# ----------------------------------------------------------------- scaling --
+def scaling_entry(curve, value, ref, world, how, detail):
+    """{ref_1gpu, speedup, efficiency} of one curve at this N: speedup =
+    value / ref_1gpu, efficiency = speedup / N (strong scaling: the same total
+    work N times faster; weak scaling: N times the work in the same time --
+    `value` is the whole-job rate in both).  None when a leg was skipped."""
+    if value is None or ref is None or ref <= 0:
+        return None
+    out = {'curve': curve, 'n_gpus': world, 'value': value, 'ref_1gpu': ref,
+           'speedup': value / ref, 'efficiency': value / ref / world,
+           'ref_measured': how}
+    if detail:
+        out['ref_detail'] = detail
+    return out
+
+
+def general_path_count(be, n):
+    """Walker evaluations of the engine's stepping kernels that left the
+    sorted-row pair sums for the general one since the engine was created
+    (equilibration included; a device counter): evidence of which code the
+    timed kernel ran."""
+    eng = be.engine(n)
+    f = getattr(eng, 'general_path_walkers', None)
+    return None if f is None else int(f(reset=False))
+
+
 # ------------------------------------------------------------------- main ---
 def run_rank(args):
     # stdout carries ONE JSON line and nothing else: libraries that print to
@@ -790,6 +866,13 @@ def run_rank(args):
 
     n, W = args.bosons, args.chains
     out = None
+    # the two curves, under the same keys at every --gpus (see the docstring)
+    key_v = f'vmc_n{n}_weak'
+    key_d = f'dmc_n{args.c4_bosons}_strong'
+    curves = {key_v: None, key_d: None}
+    ref_v = ref_d = None              # 1-GPU reference points of this run
+    ref_how = 'this run (N = 1)'
+    ref_detail = None
     if world == 1:
         # ---- headline: VMC, configs[1] ----
         m = bench_vmc(be, args, rank, world, use_pg, n, W)
@@ -797,6 +880,8 @@ def run_rank(args):
                      VMC_E_WINDOW, args)
         check_window('VMC acceptance', m['accept_rate'], VMC_ACC_WINDOW, args)
         out = vmc_line(args, m, n, W, world)
+        curves[key_v] = ref_v = out['value']
+        out['extra']['general_path_walkers'] = general_path_count(be, n)
         if not args.no_dmc:
             out['extra']['dmc'] = bench_dmc_single(be, args, n, m['vmc'],
                                                    args.dmc_walkers)
@@ -820,6 +905,7 @@ def run_rank(args):
             out['extra']['c4_dmc_sharded'] = dict(
                 s, note='the --gpus N > 1 headline workload on ONE GPU: the '
                         'strong-scaling reference point')
+            curves[key_d] = ref_d = s['walker_steps_per_s']
         if not args.no_cpu and rank == 0:
             spec = box_spec(n)
             out['cpu_baseline'] = cpu_baseline(args, spec, n,
@@ -828,6 +914,7 @@ def run_rank(args):
         # ---- headline: ONE sharded DMC population, configs[3] ----
         s = bench_dmc_sharded(be, args, rank, world, use_pg)
         out = sharded_line(args, s, world)
+        curves[key_d] = out['value']
         if be.has_vmc and not args.no_vmc_extra:
             m = bench_vmc(be, args, rank, world, use_pg, n, W)
             lv = vmc_line(args, m, n, W, world)
@@ -838,7 +925,37 @@ def run_rank(args):
                 'energy_per_particle': m['energy_per_particle'],
                 'accept_rate': m['accept_rate'],
             }
+            curves[key_v] = lv['value']
             m['vmc'].close()
+        if not args.no_scaling_ref:
+            # The 1-GPU reference points, in this run, on this box: rank 0
+            # alone runs the WHOLE population of configs[3] (and one rank's
+            # VMC share) through the same code while the other ranks wait at
+            # the barrier below.
+            ref_how = ('same run: rank 0 alone on its GPU, the other ranks '
+                       'idle at a barrier')
+            if rank == 0:
+                s1 = bench_dmc_sharded(be, args, 0, 1, False, solo=True)
+                ref_d = s1['walker_steps_per_s']
+                ref_detail = {k: s1.get(k) for k in (
+                    'ms_per_step', 'evolve_kernel_ms', 'mean_walkers',
+                    'energy_per_particle', 'hbm_achieved_GBs')}
+                if be.has_vmc and not args.no_vmc_extra:
+                    m1 = bench_vmc(be, args, 0, 1, False, n, W)
+                    ref_v = W * args.steps / m1['dt']
+                    m1['vmc'].close()
+            dist.barrier()
+            be.sync()
+    out['extra']['curves'] = curves
+    out['extra']['curves_note'] = (
+        f'{key_v}: VMC N={n}, {W} chains PER GPU, whole-job walker-steps/s '
+        f'(weak scaling); {key_d}: DMC N={args.c4_bosons}, ONE population of '
+        f'{args.c4_walkers} walkers over all GPUs (strong scaling); same keys '
+        f'at every --gpus, `value` is {key_v if world == 1 else key_d} here')
+    out['extra']['strong_scaling'] = scaling_entry(
+        key_d, curves[key_d], ref_d, world, ref_how, ref_detail)
+    out['extra']['weak_scaling'] = scaling_entry(
+        key_v, curves[key_v], ref_v, world, ref_how, None)
     # which engine produced the line (the CPU stand-in of tests/ says so)
     out['backend'] = getattr(be, 'name', 'hip')
     out['data'] = getattr(be, 'data', 'synthetic')

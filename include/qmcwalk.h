@@ -105,6 +105,11 @@ typedef struct {
 
 const char *qmc_last_error(void);
 int qmc_abi_version(void);
+/* Identity of the kernels this library was built from: the first 16 hex digits
+ * of sha256 over csrc/ sources + compiler flags (csrc/Makefile).  Measurement
+ * records (profiles/traffic.json) carry it, so that a figure measured on other
+ * kernels is recognised as stale. */
+const char *qmc_source_hash(void);
 int qmc_device_count(int *count);
 
 /* Diagnostic (no GPU needed): the piecewise-polynomial table of the one-body
@@ -178,6 +183,14 @@ const char *qmc_section_name(int32_t section);
  * runs cut at successive marks give per-section executed instructions.  The
  * shipped library returns an error. */
 int qmc_engine_section_cut(qmc_engine *eng, int32_t section);
+/* Diagnostic counters of the shipped kernels (test-visible evidence of which
+ * code path ran; no reference counterpart).  out[0]: walkers of the
+ * one-wavefront-per-walker shapes (33 <= N <= 128) that failed the per-walker
+ * checks of the sorted-row pair sums (csrc/qmc_sorted64.h, qmc_sorted128.h) in
+ * a VMC / DMC stepping kernel and were evaluated by the general pair sum
+ * inside the same kernel, since the last reset.  n <= 4; synchronises. */
+int qmc_engine_diag_counters(qmc_engine *eng, uint64_t *out, int32_t n,
+                             int32_t reset);
 
 /* Stands in for model.core_funcs.{wf_abs_log, energy, drift,
  * ith_energy_and_drift} (qmc_base/jastrow/model.py:298-366, 476-564, 756-773,

@@ -69,6 +69,13 @@ SPECS = {
     'odd24': dict(lattice_depth=30.0, lattice_ratio=2.5,
                   interaction_strength=0.7, boson_number=24,
                   supercell_size=17.5, tbf_contact_cutoff=8.75),
+    # (round 4, appended so that the random streams of the tags above do not
+    # move) sizes of the padded sorted-row shapes of the device engine: rings
+    # of 37 / 48 lanes, 50 / 63 lanes with two particles each
+    'box37': box_spec(37),
+    'box48': box_spec(48),
+    'box100': box_spec(100),
+    'box126': box_spec(126),
 }
 
 

@@ -65,6 +65,7 @@ class DmcEstParams(C.Structure):
 SIGNATURES = {
     'qmc_last_error': (C.c_char_p, []),
     'qmc_abi_version': (C.c_int, []),
+    'qmc_source_hash': (C.c_char_p, []),
     'qmc_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'qmc_model_one_body_table_info': (C.c_int, [C.POINTER(ModelParams),
                                                 C.POINTER(C.c_int32),
@@ -86,6 +87,8 @@ SIGNATURES = {
                                              C.c_int32]),
     'qmc_section_name': (C.c_char_p, [C.c_int32]),
     'qmc_engine_section_cut': (C.c_int, [_vp, C.c_int32]),
+    'qmc_engine_diag_counters': (C.c_int, [_vp, C.POINTER(C.c_uint64),
+                                           C.c_int32, C.c_int32]),
     'qmc_engine_sync': (C.c_int, [_vp]),
     'qmc_engine_timer_start': (C.c_int, [_vp]),
     'qmc_engine_timer_stop': (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -193,6 +196,12 @@ def check(rc):
 def ptr(a, typ=_dp):
     """numpy array (or None) -> typed pointer."""
     return None if a is None else a.ctypes.data_as(typ)
+
+
+def source_hash() -> str:
+    """Identity of the kernels the loaded library was built from
+    (qmc_source_hash: sha256 over csrc/ sources + flags, 16 hex digits)."""
+    return load().qmc_source_hash().decode()
 
 
 def device_count():

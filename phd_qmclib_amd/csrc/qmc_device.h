@@ -47,6 +47,7 @@
 // of runs cut at successive marks differ by what a section executes.
 #define QMC_NSEC 32
 #define QMC_SEC_COPIES 1024
+#define QMC_NDIAG 4          // diagnostic counters (DevModel::diag)
 #if defined(QMC_TIMING)
 #define QMC_SECTION(name) qmc_stamp(m, qmc_sec_id(name))
 #define QMC_SECTION_PHASE(off) qmc_stamp_phase(off)
@@ -112,6 +113,8 @@ struct DevModel {
     // v = (no wrap, d > 0), (no wrap, d < 0), (D > L/2), (D < -L/2)
     double var_cos[4], var_sin[4];
     double m_k2;           // -k2
+    double m_k2_over_a;    // -k2 / a_long, a_long^2 (qmc_sorted64.h: Own64)
+    double a_long_sq;
     double sin_rm;         // sin(pi rm / L)
     double a_long, b_long; // (pi/L) beta, (pi/L)^2 beta
     double inv_beta;       // 1 / beta
@@ -145,6 +148,11 @@ struct DevModel {
     // QMC_SEC_COPIES (every wavefront adding into ONE set of counters
     // serialises on the atomics: the kernel ran 30x slower)
     unsigned long long *sec_prof;
+    // diagnostic counters (qmc_engine_diag_counters; always allocated):
+    // [0] walkers of the stepping kernels' sorted-row shapes that failed the
+    // once-per-walker checks and were evaluated by eval_walker (the cold path;
+    // counted there, nothing is added to the sorted-row path)
+    unsigned long long *diag;
 };
 
 #if defined(QMC_TIMING)
@@ -1161,13 +1169,22 @@ template <int G, int P, bool ZCLASS>
 struct GroupLds {
     static constexpr int DUP = (P >= 8) ? QMC_DUP8 : ((P >= 2) ? 1 : 2);
     static constexpr int ROW = DUP * G * P;
-    // (the sorted-lane path of the one-particle-per-lane shape, qmc_sorted64.h,
-    // needs 5 rows of 96 entries: inside the 4 x 128 of this layout)
+    // (the stepping kernels allocate the larger of this layout and the
+    // sorted-row one, qmc_kernels.h: StepLds)
     static constexpr int DOUBLES = (ZCLASS ? 5 : 4) * ROW;
 };
 
 // Evaluate one walker held in registers.
-//   z[P]      : positions owned by this lane (particle index gl + G*a)
+//   z[P]      : positions owned by this lane (particle index gl + G*a), inside
+//               [0, L): what the pair tables are built from
+//   z1[P]     : the same particles as the one-body factor sees them -- the
+//               positions as the caller gave them.  The reference's pair
+//               distances are minimum images (periodic in L) but its one-body
+//               factor takes z mod 1 of the raw position (mrbp_qmc/model.py:
+//               417, 440): in a supercell that is not a whole number of lattice
+//               periods a particle outside the box does not see what its image
+//               inside sees.  Everywhere but the evaluation of a
+//               caller-supplied configuration z1 is z itself (same registers).
 //   F[P]      : out, drift of the own particles
 //   eith[P]   : out if ITH, local energy per particle
 //   E         : out if EN, local energy of the walker (same value in every lane)
@@ -1180,7 +1197,8 @@ struct GroupLds {
 template <int G, int P, bool PAD, bool WF, bool ITH, bool ZCLASS,
           typename R = double, bool EN = true, bool REUSE = false>
 __device__ __forceinline__ void eval_walker(const DevModel &m,
-                                            const double (&z)[P], int gl,
+                                            const double (&z)[P],
+                                            const double (&z1)[P], int gl,
                                             double *lds, double (&F)[P],
                                             double (&eith)[P], double &E,
                                             double &logwf)
@@ -1251,7 +1269,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
         if (!m.is_free && m.ob_table) {
             double ldz = 0.0, lf = 0.0;
             bool barrier;
-            one_body_tab<WF, EN>(m, z[a], ldz, lf, barrier);
+            one_body_tab<WF, EN>(m, z1[a], ldz, lf, barrier);
             if (!EN) {
                 if (WF && ok[a]) xoff_sum -= lf;
             } else if (WAVE_COUNT && !ITH && m.uniform_barrier) {
@@ -1264,7 +1282,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
                 if (WF) xoff_sum -= lf;
             } else if (ok[a]) {
                 const double kp =
-                    fma(ldz, ldz, one_body_kin_const(m, z[a], barrier));
+                    fma(ldz, ldz, one_body_kin_const(m, z1[a], barrier));
                 F[a] = ldz;
                 if (ITH) kin1[a] = kp; else kin1_sum += kp;
                 // log f1 joins the sum of split-off exponents (subtracted)
@@ -1272,7 +1290,7 @@ __device__ __forceinline__ void eval_walker(const DevModel &m,
             }
         } else if (!m.is_free) {
             double ldz, kp, f1, xoff;
-            one_body(m, z[a], ldz, kp, f1, xoff);
+            one_body(m, z1[a], ldz, kp, f1, xoff);
             if (ok[a]) {
                 if (EN) {
                     F[a] = ldz;

@@ -57,12 +57,17 @@ __device__ __forceinline__ long long walker_of_block(unsigned b, int grp)
 template <int G, int P, bool PAD, bool ZC>
 struct StepLds {
     // (+ one row of partner sums, qmc_sorted64.h: QMC_T_LDS)
-    static constexpr int DOUBLES =
+    static constexpr int SORTED =
         (QMC_SORTED128 && G == 64 && P == 2 && !ZC)
             ? 5 * SortedRows<128>::ROW
             : (QMC_SORTED64 && G == 64 && P == 1 && !ZC)
                   ? (QMC_T_LDS ? 6 : 5) * SortedRows<64>::ROW
-                  : GroupLds<G, P, ZC>::DOUBLES;
+                  : 0;
+    // a walker that fails the per-walker checks of the sorted-row path runs
+    // eval_walker on the same LDS region: room for the larger of the two
+    // layouts (N <= 64: 485 doubles sorted, 512 general -- ADVICE r3)
+    static constexpr int GENERAL = GroupLds<G, P, ZC>::DOUBLES;
+    static constexpr int DOUBLES = SORTED > GENERAL ? SORTED : GENERAL;
 };
 
 // a wave-uniform 64-bit value as the compiler can see it (scalar registers)
@@ -141,13 +146,17 @@ evaluate_kernel(const DevModel *__restrict__ mp, EvalArgs a)
     const bool active = w < a.nconf;
     if (GPB == 1 && !active) return;      // (no one else in the workgroup)
     const long long wr = active ? w : 0;
-    double z[P], F[P], ei[P], E, wf;
+    double z[P], z1[P], F[P], ei[P], E, wf;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = lane_particle<G, P, PAD>(m, gl, p);
-        z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+        // (any position is accepted, as by the reference's functions: pair
+        // tables from the image inside the box, one-body factor from the
+        // position as given -- eval_walker)
+        z1[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+        z[p] = wrap_box(z1[p], m.L);
     }
-    eval_walker<G, P, PAD, true, true, ZC, R>(m, z, gl, lds, F, ei, E, wf);
+    eval_walker<G, P, PAD, true, true, ZC, R>(m, z, z1, gl, lds, F, ei, E, wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -188,13 +197,15 @@ prepare_kernel(const DevModel *__restrict__ mp, PrepArgs a)
     const bool active = w < a.nconf;
     if (GPB == 1 && !active) return;      // (no one else in the workgroup)
     const long long wr = active ? w : 0;
-    double z[P], F[P], ei[P], E, wf;
+    double z[P], z1[P], F[P], ei[P], E, wf;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = lane_particle<G, P, PAD>(m, gl, p);
-        z[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+        z1[p] = (i < m.n) ? a.pos[wr * m.n + i] : 0.0;
+        z[p] = wrap_box(z1[p], m.L);
     }
-    eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei, E, wf);
+    eval_walker<G, P, PAD, false, false, ZC, R>(m, z, z1, gl, lds, F, ei, E,
+                                                wf);
     if (!active) return;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -246,6 +257,8 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    static_assert(StepLds<G, P, PAD, ZC>::DOUBLES >= GroupLds<G, P, ZC>::DOUBLES,
+                  "eval_walker is the fallback on the same LDS region");
     double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
     const long long w = walker_of_block<GPB>(blockIdx.x, grp);
     const bool active = w < a.W;
@@ -275,6 +288,7 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     int labn[P];              // original particle index held by each lane
     double ua = 1.0;          // accept uniform (particle 0's spare double)
     double mine = -1.0;       // >= 0 only in the lane that holds particle 0
+    bool outside = false;     // forced yield: a particle given outside [0, L)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int i = lane_particle<G, P, PAD>(m, gl, p);
@@ -301,8 +315,14 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
                 mine = (li == 0u) ? u1 : mine;
             }
         }
-        // mrbp_qmc/vmc.py:215-233 (recast to the supercell)
-        zn[p] = forced ? zp : wrap_box(zp + d, m.L);
+        // mrbp_qmc/vmc.py:215-233 (recast to the supercell).  The forced
+        // first yield (d = 0): the reference takes `ini_sys_conf` as it
+        // comes; the pair sums here want positions inside [0, L), so they get
+        // the image inside the box (and the one-body factor the position as
+        // given, below).  The stored configuration stays as the caller gave
+        // it until the first accepted move.
+        zn[p] = wrap_box(zp + d, m.L);
+        if (forced) outside = outside || zn[p] != zp;
     }
     QMC_SECTION("resort");
     // (one odd-even pass every QMC_RESORT_EVERY steps keeps the lanes sorted
@@ -313,15 +333,27 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     // (66 <= N <= 126, N even, as well: N / 2 lanes with two particles each)
     constexpr bool S128 = QMC_SORTED128 && G == 64 && P == 2 && !ZC;
     bool fast = false;
+    // (an initial configuration with a particle outside the box: the row in
+    // memory is ordered by the positions as given, not by their images, and
+    // the one-body factor wants the position as given -- the general path,
+    // which takes any order, evaluates it; wave-uniform, first yield only)
+    if (forced)
+        outside = __builtin_amdgcn_ballot_w64(outside) != 0ull;
     if constexpr (S64) {
-        fast = !m.is_ideal && sort_lanes64(zn[0], labn[0], gl, PAD ? n : 64) &&
+        fast = !m.is_ideal && !outside &&
+               sort_lanes64(zn[0], labn[0], gl, PAD ? n : 64) &&
                (PAD ? far_partner_ok_ring(m, zn[0], gl, n)
                     : far_partner_ok64(m, zn[0], gl));
     } else if constexpr (S128) {
-        fast = !m.is_ideal && (!PAD || (n & 1) == 0) &&
+        fast = !m.is_ideal && !outside && (!PAD || (n & 1) == 0) &&
                sort_rows128(zn, labn, gl, PAD ? n / 2 : 64) &&
                (PAD ? far_partner_ok_ring128(m, zn, gl, n / 2)
                     : far_partner_ok128(m, zn, gl));
+    }
+    if constexpr (S64 || S128) {
+        // (diagnostic, cold path only: walkers that leave the sorted-row path)
+        if (!fast && !m.is_ideal && gl == 0 && active)
+            atomicAdd(m.diag, 1ull);
     } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         // ascending order, wrap point anchored at the lane seam (qmc_device.h)
         // (one particle per lane: lanes 0 .. n-1 hold them)
@@ -350,12 +382,22 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
         if constexpr (S128)
             eval_sorted128<R, true, !TWO_PASS, false, PAD>(m, zn, gl, lds, F,
                                                            e_new, wf_new);
-    } else if constexpr (TWO_PASS)
-        eval_walker<G, P, PAD, true, false, ZC, R, false, false>(
-            m, zn, gl, lds, F, ei, e_new, wf_new);
-    else
-        eval_walker<G, P, PAD, true, false, ZC, R>(m, zn, gl, lds, F, ei,
-                                                   e_new, wf_new);
+    } else {
+        // (the general path; z1: see eval_walker -- the stored positions on
+        // a first yield given outside the box, nothing was reordered then)
+        double z1[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int i = lane_particle<G, P, PAD>(m, gl, p);
+            z1[p] = (outside && i < n) ? a.pos[wr * n + i] : zn[p];
+        }
+        if constexpr (TWO_PASS)
+            eval_walker<G, P, PAD, true, false, ZC, R, false, false>(
+                m, zn, z1, gl, lds, F, ei, e_new, wf_new);
+        else
+            eval_walker<G, P, PAD, true, false, ZC, R>(m, zn, z1, gl, lds, F,
+                                                       ei, e_new, wf_new);
+    }
     QMC_SECTION("metropolis+store");
     if (!forced) {
         if (!LEAN && a.tape) {
@@ -405,9 +447,16 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
                 if constexpr (S128)
                     eval_sorted128<R, false, true, true, PAD>(
                         m, zn, gl, lds, F, e_new, wf_unused);
-            } else
+            } else {
+                double z1[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    int i = lane_particle<G, P, PAD>(m, gl, p);
+                    z1[p] = (outside && i < n) ? a.pos[wr * n + i] : zn[p];
+                }
                 eval_walker<G, P, PAD, false, false, ZC, R, true, true>(
-                    m, zn, gl, lds, F, ei, e_new, wf_unused);
+                    m, zn, z1, gl, lds, F, ei, e_new, wf_unused);
+            }
             QMC_SECTION_PHASE(0);
             QMC_SECTION("store");
         }
@@ -419,7 +468,10 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
                 a.label[w * n + i] = (unsigned short)labn[p];
             }
         }
-        if (!forced) wf_cur = wf_new;
+        // (the initial yield too: log|psi| of the initial state then comes
+        // from the same pair sum as every later one -- the sorted-row path on
+        // its shapes -- instead of qmc_vmc_set_state's batch evaluation)
+        wf_cur = wf_new;
         e_cur = e_new;       // energy only re-evaluated on accepted moves
     }                        // (qmc_base/jastrow/vmc.py:253-262)
     if (!LEAN && a.ser_pos) {
@@ -429,9 +481,11 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             // series in the original particle order (a rejected move leaves
             // pos / label as they were: read them back)
             if (i < n) {
-                const int lb = acc ? labn[p] : (int)a.label[w * n + i];
+                // (the forced first yield: the configuration as it was given)
+                const bool moved = acc && !forced;
+                const int lb = moved ? labn[p] : (int)a.label[w * n + i];
                 a.ser_pos[(a.y * a.W + w) * n + lb] =
-                    acc ? zn[p] : a.pos[w * n + i];
+                    moved ? zn[p] : a.pos[w * n + i];
             }
         }
     }
@@ -496,6 +550,8 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    static_assert(StepLds<G, P, PAD, ZC>::DOUBLES >= GroupLds<G, P, ZC>::DOUBLES,
+                  "eval_walker is the fallback on the same LDS region");
     double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
     const long long s = walker_of_block<GPB>(blockIdx.x, grp);
     const long long nw = a.ctl->nw;
@@ -568,6 +624,11 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
                sort_rows128(z, lab, gl, PAD ? n / 2 : 64) &&
                (PAD ? far_partner_ok_ring128(m, z, gl, n / 2)
                     : far_partner_ok128(m, z, gl));
+    }
+    if constexpr (S64 || S128) {
+        // (diagnostic, cold path only: walkers that leave the sorted-row path)
+        if (!fast && !m.is_ideal && gl == 0 && active)
+            atomicAdd(m.diag, 1ull);
     } else if constexpr (G == 64 && P == 1 && QMC_LINEAR_ORDER) {
         anchor_seam(z[0], lab[0], n);
         if ((step % QMC_RESORT_EVERY) == 0)
@@ -598,7 +659,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
             eval_sorted128<R, false, true, false, PAD>(m, z, gl, lds, F,
                                                        e_next, wf);
     } else
-        eval_walker<G, P, PAD, false, false, ZC, R>(m, z, gl, lds, F, ei,
+        eval_walker<G, P, PAD, false, false, ZC, R>(m, z, z, gl, lds, F, ei,
                                                     e_next, wf);
     QMC_SECTION("weight+store");
     if (!active) return;

@@ -22,6 +22,25 @@
 
 #include "qmc_sorted64.h"
 
+// the two table entries of a lane (slots 2 l, 2 l + 1) in one LDS access:
+// ds_read_b128 in double (the rows keep the pairs 16-byte aligned,
+// SortedRows<128>), ds_read_b64 in float
+#ifndef QMC_S128_SU_PAIRS
+#define QMC_S128_SU_PAIRS 1
+#endif
+template <typename R> struct SlotPair;
+template <> struct SlotPair<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+};
+template <> struct SlotPair<float> {
+    typedef float type __attribute__((ext_vector_type(2)));
+};
+template <typename R>
+__device__ __forceinline__ typename SlotPair<R>::type ld_pair(const R *p)
+{
+    return *(const typename SlotPair<R>::type *)p;
+}
+
 // ---- exact order of a row of 128 slots, two per lane ------------------------
 // ascending: z0 <= z1 inside every lane and z1 <= the next lane's z0
 __device__ __forceinline__ bool rows_ascending128(const double (&z)[2],
@@ -101,7 +120,7 @@ __device__ __forceinline__ bool far_partner_ok_ring128(const DevModel &m,
 }
 
 // One walker on an ascending row of 128 slots.  z[2]: the lane's particles
-// (slots 2 gl, 2 gl + 1); lds: the 5 rows of sorted_particle_setup (192 entries
+// (slots 2 gl, 2 gl + 1); lds: the 5 rows of sorted_particle_setup (194 entries
 // each).
 //   PAD : N < 128 particles, N even: the first nl = N / 2 lanes hold two each
 //         (see eval_sorted64 for what changes on a ring shorter than the wave)
@@ -127,10 +146,36 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     QMC_SECTION("tables+onebody");
     Own64<R> o[2];
     SortedOneBody ob[2];
+    PTab ta[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
-        sorted_particle_setup<R, WF, EN, REUSE, NS>(m, z[a], 2 * gl + a,
-                                                    (R *)lds, o[a], ob[a], n);
+        sorted_particle_setup<R, WF, EN, REUSE, NS, false>(
+            m, z[a], 2 * gl + a, (R *)lds, o[a], ob[a], n, ta[a]);
+    if (!REUSE && live) {
+        // both entries of the lane with one 16-byte store per row; the pair one
+        // period below for the lanes the rotation reaches around the row's end
+        typedef typename SlotPair<R>::type R2;
+        const int up = H + 2 * gl, lo = up - n;
+#define QMC_S128_ST(row, i, v0, v1)                                           \
+        *(R2 *)((row) + (i)) = R2{ (R)(v0), (R)(v1) }
+        QMC_S128_ST(lS, up, ta[0].s, ta[1].s);
+        QMC_S128_ST(lC, up, ta[0].c, ta[1].c);
+        QMC_S128_ST(lSU, up, ta[0].su, ta[1].su);
+        QMC_S128_ST(lCU, up, ta[0].cu, ta[1].cu);
+        QMC_S128_ST(lZ, up, z[0], z[1]);
+        if (lo >= 2) {
+            QMC_S128_ST(lS, lo, -ta[0].s, -ta[1].s);
+            QMC_S128_ST(lC, lo, -ta[0].c, -ta[1].c);
+            QMC_S128_ST(lSU, lo,
+                        fma(ta[0].su, m.cth, -(ta[0].cu * m.sth_signed)),
+                        fma(ta[1].su, m.cth, -(ta[1].cu * m.sth_signed)));
+            QMC_S128_ST(lCU, lo,
+                        fma(ta[0].cu, m.cth, ta[0].su * m.sth_signed),
+                        fma(ta[1].cu, m.cth, ta[1].su * m.sth_signed));
+            QMC_S128_ST(lZ, lo, z[0] - m.L, z[1] - m.L);
+        }
+#undef QMC_S128_ST
+    }
     if (!REUSE) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -157,7 +202,9 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
          : (double)group_ror1<G>(T))
 #define QMC_S128_ALL(cond)                                                    \
     ((__builtin_amdgcn_ballot_w64(cond) | ~live_mask) == ~0ull)
-    R Fr[2] = { (R)ob[0].ldz, (R)ob[1].ldz };  // drift: one-body + quotients
+    R Fr[2] = { 0, 0 };      // drift: pair quotients in units of a_long (Own64)
+    // (one register pair across the loops instead of two)
+    const double kin1_sum = ob[0].kin1 + ob[1].kin1;
     R T[2] = { 0, 0 };       // travelling sums for the partner lane's particles
     R Qall = 0, Qs = 0;      // sum of q^2 over all / short pairs
     R PS = 1, PL = 1;        // products: short factors f2, |Y| of all pairs
@@ -172,15 +219,21 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     if (EN) X = (oa).ks0 * (bcu) - (oa).kc0 * (bsu);
     // a pair of a general step: class from the sine, short ones recomputed in
     // an exec-masked region
-#define QMC_S128_XY(oa, cs, cc, sup, cup, X, Y, sh)                           \
+    // (bsu, bcu: the partner's k2-table entry.  QMC_S128_SU_PAIRS: read for
+    // both partner slots with one 16-byte access per row at the top of the
+    // step -- a step of the general phase nearly always has short pairs in some
+    // lane, an LDS instruction costs the same for one lane as for 64, and a
+    // read inside the exec-masked region is a lane-stride-16 access (2-way
+    // bank conflict) whose latency nothing hides; 0: read where it is used)
+#define QMC_S128_XY(oa, cs, cc, bsu, bcu, X, Y, sh)                           \
     const R Y##_s = (oa).s * (cc) - (oa).c * (cs);   /* sin(pi D' / L) >= 0 */ \
     R X = 0;                                                                  \
-    if (EN) X = (oa).akc * (cc) + (oa).aks * (cs);                            \
+    if (EN) X = (oa).c * (cc) + (oa).s * (cs);       /* cos(pi D' / L) */      \
     const bool sh = q_abs(Y##_s) < sin_rm;           /* D' < rm */             \
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \
         asm volatile("");                                                     \
-        const R bsu_ = *(sup), bcu_ = *(cup);                                 \
+        const R bsu_ = (bsu), bcu_ = (bcu);                                   \
         Y = (oa).c0 * bcu_ + (oa).s0 * bsu_;                                  \
         if (EN) X = (oa).ks0 * bcu_ - (oa).kc0 * bsu_;                        \
     }
@@ -189,7 +242,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     QMC_SECTION("pairs_in_lane");
     {
         const R cs = (R)o[0].s, cc = (R)o[0].c;
-        QMC_S128_XY(o[1], cs, cc, pSU, pCU, X, Y, sh)
+        QMC_S128_XY(o[1], cs, cc, pSU[0], pCU[0], X, Y, sh)
         // (the products of an idle lane never reach the sums: its log is dropped)
         if (WF) { PL *= Y; if (sh) { asm volatile(""); PS *= Y; } }
         if (EN) {
@@ -228,24 +281,23 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     }
     {
         // set A: step k, set B: step k + 1 (entries of both partner particles)
-        R asu0 = pSU[-2], acu0 = pCU[-2], asu1 = pSU[-1], acu1 = pCU[-1];
+        typedef typename SlotPair<R>::type R2;
+        R2 asu = ld_pair(pSU - 2), acu = ld_pair(pCU - 2);
         R az = pZ[-2];
-        R bsu0 = pSU[-4], bcu0 = pCU[-4], bsu1 = pSU[-3], bcu1 = pCU[-3];
+        R2 bsu = ld_pair(pSU - 4), bcu = ld_pair(pCU - 4);
         R bz = pZ[-4];
         // (the farthest pair of a step: own slot 1 against the partner's slot 0)
         const R zt = o[1].zt;
 #pragma clang loop unroll(disable)
         while (k < kfull) {
             if (!QMC_S128_ALL(az > zt)) break;
-            QMC_S128_LEAD(asu0, acu0, asu1, acu1)
-            asu0 = pSU[-2 * (k + 2)]; acu0 = pCU[-2 * (k + 2)];
-            asu1 = pSU[-2 * (k + 2) + 1]; acu1 = pCU[-2 * (k + 2) + 1];
+            QMC_S128_LEAD(asu[0], acu[0], asu[1], acu[1])
+            asu = ld_pair(pSU - 2 * (k + 2)); acu = ld_pair(pCU - 2 * (k + 2));
             az = pZ[-2 * (k + 2)];
             ++k;
             if (!QMC_S128_ALL(bz > zt)) break;
-            QMC_S128_LEAD(bsu0, bcu0, bsu1, bcu1)
-            bsu0 = pSU[-2 * (k + 2)]; bcu0 = pCU[-2 * (k + 2)];
-            bsu1 = pSU[-2 * (k + 2) + 1]; bcu1 = pCU[-2 * (k + 2) + 1];
+            QMC_S128_LEAD(bsu[0], bcu[0], bsu[1], bcu[1])
+            bsu = ld_pair(pSU - 2 * (k + 2)); bcu = ld_pair(pCU - 2 * (k + 2));
             bz = pZ[-2 * (k + 2)];
             ++k;
             if (WF) {
@@ -264,13 +316,25 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     // ---- general steps ----
     QMC_SECTION("rotation_loop_body");
     // the four pairs of a step against partner tables (s0, c0), (s1, c1)
+#if QMC_S128_SU_PAIRS
+#define QMC_S128_SU_LOAD(kk)                                                  \
+        const typename SlotPair<R>::type su_ = ld_pair(pSU - 2 * (kk)),       \
+                                         cu_ = ld_pair(pCU - 2 * (kk));
+#define QMC_S128_SU(kk, b) su_[b]
+#define QMC_S128_CU(kk, b) cu_[b]
+#else
+#define QMC_S128_SU_LOAD(kk)
+#define QMC_S128_SU(kk, b) pSU[-2 * (kk) + (b)]
+#define QMC_S128_CU(kk, b) pCU[-2 * (kk) + (b)]
+#endif
 #define QMC_S128_STEP(s0_, c0_, s1_, c1_, kk, LAST)                           \
     {                                                                         \
         const bool mine = live & (!(LAST) || gl < K);                         \
-        QMC_S128_XY(o[0], s0_, c0_, pSU - 2 * (kk), pCU - 2 * (kk), X00, Y00, h00)         \
-        QMC_S128_XY(o[1], s0_, c0_, pSU - 2 * (kk), pCU - 2 * (kk), X10, Y10, h10)         \
-        QMC_S128_XY(o[0], s1_, c1_, pSU - 2 * (kk) + 1, pCU - 2 * (kk) + 1, X01, Y01, h01) \
-        QMC_S128_XY(o[1], s1_, c1_, pSU - 2 * (kk) + 1, pCU - 2 * (kk) + 1, X11, Y11, h11) \
+        QMC_S128_SU_LOAD(kk)                                                  \
+        QMC_S128_XY(o[0], s0_, c0_, QMC_S128_SU(kk, 0), QMC_S128_CU(kk, 0), X00, Y00, h00) \
+        QMC_S128_XY(o[1], s0_, c0_, QMC_S128_SU(kk, 0), QMC_S128_CU(kk, 0), X10, Y10, h10) \
+        QMC_S128_XY(o[0], s1_, c1_, QMC_S128_SU(kk, 1), QMC_S128_CU(kk, 1), X01, Y01, h01) \
+        QMC_S128_XY(o[1], s1_, c1_, QMC_S128_SU(kk, 1), QMC_S128_CU(kk, 1), X11, Y11, h11) \
         if (WF && mine) {                                                     \
             PL *= (Y00 * Y10) * (Y01 * Y11);                                  \
             if (h00) { asm volatile(""); PS *= Y00; }                         \
@@ -313,10 +377,10 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         const R Y11 = o[1].s * (c1_) - o[1].c * (s1_);                        \
         if (WF && live) PL *= (Y00 * Y10) * (Y01 * Y11);                      \
         if (EN) {                                                             \
-            const R q00 = pair_div(o[0].akc * (c0_) + o[0].aks * (s0_), Y00); \
-            const R q10 = pair_div(o[1].akc * (c0_) + o[1].aks * (s0_), Y10); \
-            const R q01 = pair_div(o[0].akc * (c1_) + o[0].aks * (s1_), Y01); \
-            const R q11 = pair_div(o[1].akc * (c1_) + o[1].aks * (s1_), Y11); \
+            const R q00 = pair_div(o[0].c * (c0_) + o[0].s * (s0_), Y00);   \
+            const R q10 = pair_div(o[1].c * (c0_) + o[1].s * (s0_), Y10);   \
+            const R q01 = pair_div(o[0].c * (c1_) + o[0].s * (s1_), Y01);   \
+            const R q11 = pair_div(o[1].c * (c1_) + o[1].s * (s1_), Y11);   \
             Fr[0] += q00 + q01;                                               \
             Fr[1] += q10 + q11;                                               \
             T[0] -= q00 + q10;                                                \
@@ -328,10 +392,9 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         }                                                                     \
     }
     {
-        R as0 = pS[-2 * k], ac0 = pC[-2 * k];
-        R as1 = pS[-2 * k + 1], ac1 = pC[-2 * k + 1];
-        R bs0 = pS[-2 * (k + 1)], bc0 = pC[-2 * (k + 1)];
-        R bs1 = pS[-2 * (k + 1) + 1], bc1 = pC[-2 * (k + 1) + 1];
+        typedef typename SlotPair<R>::type R2;
+        R2 as = ld_pair(pS - 2 * k), ac = ld_pair(pC - 2 * k);
+        R2 bs = ld_pair(pS - 2 * (k + 1)), bc = ld_pair(pC - 2 * (k + 1));
         // the nearest pair of a step: own slot 0 against the partner's slot 1;
         // once it is long-range for every lane, so is every later pair
         const R zt0 = o[0].zt;
@@ -340,13 +403,11 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             if (__builtin_amdgcn_ballot_w64(live & (pZ[-2 * k + 1] > zt0)) ==
                 0ull)
                 break;
-            QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
-            as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
-            as1 = pS[-2 * (k + 2) + 1]; ac1 = pC[-2 * (k + 2) + 1];
-            QMC_S128_STEP(bs0, bc0, bs1, bc1, k + 1, false)
-            // (k + 3 <= G/2 + 1: inside the doubled tables)
-            bs0 = pS[-2 * (k + 3)]; bc0 = pC[-2 * (k + 3)];
-            bs1 = pS[-2 * (k + 3) + 1]; bc1 = pC[-2 * (k + 3) + 1];
+            QMC_S128_STEP(as[0], ac[0], as[1], ac[1], k, false)
+            as = ld_pair(pS - 2 * (k + 2)); ac = ld_pair(pC - 2 * (k + 2));
+            QMC_S128_STEP(bs[0], bc[0], bs[1], bc[1], k + 1, false)
+            // (k + 3 <= N / 4 + 2: the two unused entries in front of the rows)
+            bs = ld_pair(pS - 2 * (k + 3)); bc = ld_pair(pC - 2 * (k + 3));
             k += 2;
             if (WF) {
                 q_fold(PS, eS);
@@ -357,26 +418,27 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         QMC_SECTION("rotation");
 #pragma clang loop unroll(disable)
         while (k < kfull) {
-            QMC_S128_LONG_STEP(as0, ac0, as1, ac1)
-            as0 = pS[-2 * (k + 2)]; ac0 = pC[-2 * (k + 2)];
-            as1 = pS[-2 * (k + 2) + 1]; ac1 = pC[-2 * (k + 2) + 1];
-            QMC_S128_LONG_STEP(bs0, bc0, bs1, bc1)
-            bs0 = pS[-2 * (k + 3)]; bc0 = pC[-2 * (k + 3)];
-            bs1 = pS[-2 * (k + 3) + 1]; bc1 = pC[-2 * (k + 3) + 1];
+            QMC_S128_LONG_STEP(as[0], ac[0], as[1], ac[1])
+            as = ld_pair(pS - 2 * (k + 2)); ac = ld_pair(pC - 2 * (k + 2));
+            QMC_S128_LONG_STEP(bs[0], bc[0], bs[1], bc[1])
+            bs = ld_pair(pS - 2 * (k + 3)); bc = ld_pair(pC - 2 * (k + 3));
             k += 2;
             if (WF) q_fold(PL, eL);
         }
         if (k <= kfull) {
-            QMC_S128_STEP(as0, ac0, as1, ac1, k, false)
+            QMC_S128_STEP(as[0], ac[0], as[1], ac[1], k, false)
             ++k;
-            as0 = bs0; ac0 = bc0; as1 = bs1; ac1 = bc1;
+            as = bs; ac = bc;
         }
         // the final half step (an even number of lanes in use) visits every
         // pair from both sides
         QMC_SECTION("rotation_last_step");
-        if (half_last) QMC_S128_STEP(as0, ac0, as1, ac1, k, true)
+        if (half_last) QMC_S128_STEP(as[0], ac[0], as[1], ac[1], k, true)
     }
 #undef QMC_S128_STEP
+#undef QMC_S128_SU_LOAD
+#undef QMC_S128_SU
+#undef QMC_S128_CU
 #undef QMC_S128_LONG_STEP
 #undef QMC_S128_XY
 #undef QMC_S128_SHORT_XY
@@ -399,11 +461,11 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     QMC_SECTION("energy+logwf");
     double e_lane = 0.0, e_consts = 0.0;
     if (EN) {
-        F[0] = (double)Fr[0]; F[1] = (double)Fr[1];
+        F[0] = fma(m.a_long, (double)Fr[0], ob[0].ldz);
+        F[1] = fma(m.a_long, (double)Fr[1], ob[1].ldz);
         const double Qall_d = (double)Qall, Qs_d = (double)Qs;
-        const double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
-        e_lane = fma(2.0, pk, ob[0].kin1 + ob[1].kin1) - F[0] * F[0] -
-                 F[1] * F[1];
+        const double pk = (Qs_d + (Qall_d - Qs_d) * m.inv_beta) * m.a_long_sq;
+        e_lane = fma(2.0, pk, kin1_sum) - F[0] * F[0] - F[1] * F[1];
         if (PAD && !live) e_lane = 0.0;
         if (nb_counted)
             e_consts += (double)(n - nb_wave) * m.e0 +

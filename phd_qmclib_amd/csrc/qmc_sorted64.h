@@ -178,9 +178,14 @@ __device__ __forceinline__ R lds_ahead(const R *p)
 template <typename R>
 struct Own64 {
     R s, c;          // sin, cos(pi z / L)
-    R aks, akc;      // a_long times them (long-range numerator)
     R s0, c0;        // |a_m| sin, cos(k2 z - phi): Y = f2 itself for a short pair
-    R ks0, kc0;      // -k2 times them (short-range numerator)
+    // (-k2 / a_long) times them: the short-range numerator.  The pair quotients
+    // are summed in units of a_long = (pi / L) beta -- a long pair's is plain
+    // cot(pi D' / L), numerator c_i c_j + s_i s_j from the tables as they are --
+    // and the sums are scaled once at the end (F = f1'/f1 + a_long sum q,
+    // sum q^2 by a_long^2): two table registers fewer per particle than with
+    // a_long folded into a second copy of (s, c)
+    R ks0, kc0;
     R zt;            // z - rm: a partner above it is closer than rm
 };
 
@@ -206,18 +211,29 @@ struct SortedOneBody {
 // `n`: slots in use (n = NS for the exact shapes; a slot >= n writes nothing).
 // The rows carry one unused entry in front: the loops request tables up to one
 // step past their last one.
+// Two slots per lane (NS = 128): TWO unused entries in front, which keeps the
+// pair (slot 2 l, slot 2 l + 1) of a lane on a 16-byte boundary in every row --
+// the loops of qmc_sorted128.h read a partner lane's two entries with ONE
+// ds_read_b128 (two ds_read_b64 at a lane stride of 16 bytes are 2-way bank
+// conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 44 % in round 3) --
+// and keeps the look-ahead of the last trip (k + 3 = N / 4 + 2 lanes down)
+// inside the row.
 template <int NS>
 struct SortedRows {
-    static constexpr int H = NS / 2 + 1;       // offset of slot 0
+    static constexpr int H = NS / 2 + (NS > 64 ? 2 : 1);   // offset of slot 0
     static constexpr int ROW = NS + H;
+    static_assert(NS <= 64 || (H % 2 == 0 && ROW % 2 == 0),
+                  "two slots per lane: 16-byte aligned pairs");
 };
 
-template <typename R, bool WF, bool EN, bool REUSE, int NS>
+// WRITE = false: the caller publishes the entries itself from `ta` (two slots
+// per lane: both particles of a lane with one 16-byte store per row).
+template <typename R, bool WF, bool EN, bool REUSE, int NS, bool WRITE = true>
 __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double z,
                                                       int slot, R *tab,
                                                       Own64<R> &o,
                                                       SortedOneBody &ob,
-                                                      int n = NS)
+                                                      int n, PTab &ta)
 {
     constexpr int H = SortedRows<NS>::H, ROW = SortedRows<NS>::ROW;
     R *lS = tab, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
@@ -242,7 +258,6 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         if (WF) { ob.prod1 = f1; ob.xoff = xo; }
     }
     __builtin_amdgcn_sched_barrier(0);
-    PTab ta;
     if (REUSE) {
         ta.s = (double)lS[H + slot]; ta.c = (double)lC[H + slot];
         ta.su = (double)lSU[H + slot]; ta.cu = (double)lCU[H + slot];
@@ -253,19 +268,15 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         sincos_halfpi(z * m.k2_2pi, ta.su, ta.cu);
     }
     o.s = (R)ta.s; o.c = (R)ta.c;
-    if (EN) {
-        o.aks = (R)(m.a_long * ta.s);
-        o.akc = (R)(m.a_long * ta.c);
-    }
     const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
     const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
     o.s0 = (R)s0; o.c0 = (R)c0;
     if (EN) {
-        o.ks0 = (R)(m.m_k2 * s0);
-        o.kc0 = (R)(m.m_k2 * c0);
+        o.ks0 = (R)(m.m_k2_over_a * s0);
+        o.kc0 = (R)(m.m_k2_over_a * c0);
     }
     o.zt = (R)(z - m.rm);
-    if (!REUSE && slot < n) {
+    if (WRITE && !REUSE && slot < n) {
         lS[H + slot] = (R)ta.s; lC[H + slot] = (R)ta.c;
         lSU[H + slot] = (R)ta.su; lCU[H + slot] = (R)ta.cu;
         lZ[H + slot] = (R)z;
@@ -312,7 +323,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     QMC_SECTION("tables+onebody");
     Own64<R> o;
     SortedOneBody ob;
-    sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob, nl);
+    PTab ta_own;
+    sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob, nl,
+                                               ta_own);
     // (where the shares of this lane's particle arrive: its own index from the
     // lanes above it, the index one period below from the lanes that reach it
     // around the end of the row)
@@ -346,7 +359,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                __builtin_amdgcn_ds_bpermute(ring_src, __double2loint((double)(T)))) \
          : (double)group_ror1<G>(T))
 
-    R Fr = (R)ldz;           // drift: one-body term + pair quotients
+    R Fr = 0;                // drift: pair quotients, in units of a_long
     R T = 0;                 // travelling sum for the partner lane
     R Qall = 0, Qs = 0;      // sum of q^2 over all / short pairs
     R PS = 1, PL = 1;        // products: short factors f2, |Y| of all pairs
@@ -430,7 +443,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
 #define QMC_S64_XY(cs, cc, kk, LAST, X, Y, sh, mine)                          \
     const R Y##_s = o.s * (cc) - o.c * (cs);   /* sin(pi D' / L) >= 0 */       \
     R X = 0;                                                                  \
-    if (EN) X = o.akc * (cc) + o.aks * (cs);   /* a_long cos(pi D' / L) */     \
+    if (EN) X = o.c * (cc) + o.s * (cs);       /* cos(pi D' / L) */            \
     const bool mine = live & (!(LAST) || gl < K);                             \
     const bool sh = q_abs(Y##_s) < sin_rm;     /* D' < rm */                   \
     if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));           \
@@ -527,9 +540,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     QMC_SECTION("energy+logwf");
     double e_lane = 0.0, e_consts = 0.0;
     if (EN) {
-        F = (double)Fr;
+        F = fma(m.a_long, (double)Fr, ldz);
         const double Qall_d = (double)Qall, Qs_d = (double)Qs;
-        const double pk = Qs_d + (Qall_d - Qs_d) * m.inv_beta;
+        const double pk = (Qs_d + (Qall_d - Qs_d) * m.inv_beta) * m.a_long_sq;
         e_lane = fma(2.0, pk, kin1) - F * F;
         if (PAD && !live) e_lane = 0.0;
         if (nb_counted)

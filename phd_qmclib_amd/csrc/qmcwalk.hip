@@ -37,6 +37,10 @@ static int fail(const std::string &msg)
 
 extern "C" const char *qmc_last_error(void) { return g_err.c_str(); }
 extern "C" int qmc_abi_version(void) { return QMCWALK_ABI_VERSION; }
+#ifndef QMC_SRC_SHA
+#define QMC_SRC_SHA "unknown"
+#endif
+extern "C" const char *qmc_source_hash(void) { return QMC_SRC_SHA; }
 extern "C" int qmc_device_count(int *count)
 {
     HIP_TRY(hipGetDeviceCount(count));
@@ -53,6 +57,7 @@ struct qmc_engine {
     double *ob_table_dev = nullptr;     // one-body table rows (or null)
     double *trig_table_dev = nullptr;   // pair-angle row table (or null)
     unsigned long long *sec_prof_dev = nullptr;  // QMC_TIMING builds only
+    unsigned long long *diag_dev = nullptr;      // DevModel::diag (QMC_NDIAG)
     qmc_model_params mp;
     int G = 64, P = 1;
     bool pad = false;
@@ -364,6 +369,8 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     double pi_L = QMC_PI / d.L;
     d.a_long = pi_L * p.param_beta;
     d.b_long = pi_L * pi_L * p.param_beta;
+    d.a_long_sq = d.a_long * d.a_long;
+    d.m_k2_over_a = d.a_long != 0.0 ? -d.k2 / d.a_long : 0.0;
     d.beta = p.param_beta;
     d.inv_beta = p.param_beta != 0.0 ? 1.0 / p.param_beta : 0.0;
     d.log_am = log(fabs(p.param_am));
@@ -660,6 +667,10 @@ static int engine_create_impl(const qmc_model_params *model, int device,
                       QMC_NSEC * sizeof(unsigned long long)));
     e->dm.sec_prof = e->sec_prof_dev;
 #endif
+    HIP_TRY(hipMalloc((void **)&e->diag_dev,
+                      QMC_NDIAG * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e->diag_dev, 0, QMC_NDIAG * sizeof(unsigned long long)));
+    e->dm.diag = e->diag_dev;
     HIP_TRY(hipMalloc((void **)&e->dm_dev, sizeof(DevModel)));
     HIP_TRY(hipMemcpy(e->dm_dev, &e->dm, sizeof(DevModel),
                       hipMemcpyHostToDevice));
@@ -912,6 +923,24 @@ extern "C" int qmc_engine_section_cut(qmc_engine *e, int32_t section)
 #endif
 }
 
+// Diagnostic counters the kernels keep (DevModel::diag); synchronises.
+extern "C" int qmc_engine_diag_counters(qmc_engine *e, uint64_t *out,
+                                        int32_t n, int32_t reset)
+{
+    if (!e) return fail("qmc_engine_diag_counters: null engine");
+    if (n < 0 || n > QMC_NDIAG)
+        return fail("qmc_engine_diag_counters: at most 4 counters");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (out && n > 0)
+        HIP_TRY(hipMemcpy(out, e->diag_dev, (size_t)n * sizeof(uint64_t),
+                          hipMemcpyDeviceToHost));
+    if (reset)
+        HIP_TRY(hipMemset(e->diag_dev, 0,
+                          QMC_NDIAG * sizeof(unsigned long long)));
+    return 0;
+}
+
 extern "C" const char *qmc_section_name(int32_t i)
 {
     if (i < 0 || i >= QMC_NSEC) return "";
@@ -929,6 +958,7 @@ extern "C" void qmc_engine_destroy(qmc_engine *e)
     if (e->ob_table_dev) hipFree(e->ob_table_dev);
     if (e->trig_table_dev) hipFree(e->trig_table_dev);
     if (e->sec_prof_dev) hipFree(e->sec_prof_dev);
+    if (e->diag_dev) hipFree(e->diag_dev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }

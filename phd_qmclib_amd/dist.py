@@ -157,18 +157,21 @@ class DistributedDmc:
 
     def __init__(self, ensemble, num_particles: int, device,
                  rebalance_every: int = 32, imbalance_tol: float = 0.02,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, solo: bool = False):
         """`force_collectives` issues the per-step all-reduce even in a group
         of one rank (tests: the RCCL call and its stream ordering run on a
-        single GPU; a one-rank all-reduce is the identity)."""
+        single GPU; a one-rank all-reduce is the identity).  `solo`: the
+        population lives on this rank alone whatever the process group's size
+        (bench.py: the one-GPU strong-scaling reference timed by rank 0 inside
+        a multi-rank run); no collective is issued."""
         self.ens = ensemble
         self.n = int(num_particles)
         self.device = torch.device(device)
-        self.rank, self.world = _world()
+        self.rank, self.world = (0, 1) if solo else _world()
         self.rebalance_every = int(rebalance_every)
         self.imbalance_tol = float(imbalance_tol)
-        self._collect = self.world > 1 or (
-            force_collectives and dist.is_available() and dist.is_initialized())
+        self._collect = not solo and (self.world > 1 or (
+            force_collectives and dist.is_available() and dist.is_initialized()))
         self._check_stream()
         self.sums = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.steps_done = 0
@@ -220,17 +223,23 @@ class DistributedDmc:
         if ph is None:
             return None
         steps = max(ph['steps'], 1)
-        ar = [0.0]
+        ar = []
         if ph['events']:
             torch.cuda.synchronize(self.device)
             ar = [a.elapsed_time(b) * 1e3 for a, b in ph['events']]   # us
-            mean_ar = sum(ar) / len(ar)
-        else:
-            mean_ar = ph['allreduce_wall_s'] * 1e6 / steps
+        # steps beyond the event pool were timed on the host clock: the mean
+        # covers every step (events where there were events, wall clock for the
+        # rest), and the line says how many steps each clock covered
+        wall_steps = ph['steps'] - len(ar)
+        mean_ar = (sum(ar) + ph['allreduce_wall_s'] * 1e6) / steps
+        how = 'hip events on the stream' if ar else 'host wall clock'
+        if ar and wall_steps > 0:
+            how = (f'hip events on the stream ({len(ar)} steps) + host wall '
+                   f'clock ({wall_steps} steps: event pool exhausted)')
         return dict(steps=ph['steps'], allreduce_us_per_step=mean_ar,
-                    allreduce_us_max=max(ar) if ph['events'] else None,
-                    allreduce_timed_with='hip events on the stream'
-                    if ph['events'] else 'host wall clock',
+                    allreduce_us_max=max(ar) if ar else None,
+                    allreduce_event_timed_steps=len(ar),
+                    allreduce_timed_with=how,
                     host_enqueue_us_per_step=ph['host_enqueue_s'] * 1e6 / steps,
                     rebalance_ms_total=ph['rebalance_s'] * 1e3,
                     rebalance_calls=ph['rebalance_calls'])
@@ -319,9 +328,13 @@ class DistributedDmc:
         transfers, unpacking and the new population size are stream-ordered."""
         t_start = time.perf_counter()
         counts = self.global_counts()
+        self.last_counts = counts          # before any transfer
         mean = sum(counts) / len(counts)
         if not force and mean > 0 and \
                 (max(counts) - min(counts)) <= self.imbalance_tol * mean:
+            if self._phase is not None:     # (its all-gather was paid for)
+                self._phase['rebalance_s'] += time.perf_counter() - t_start
+                self._phase['rebalance_calls'] += 1
             return 0
         plan = rebalance_plan(counts)
         rec = self.record_size()
@@ -360,7 +373,6 @@ class DistributedDmc:
         self._inflight = keep
         self.walkers_moved += moved
         self.rebalances += 1 if moved else 0
-        self.last_counts = counts          # before the transfers
         if self._phase is not None:
             self._phase['rebalance_s'] += time.perf_counter() - t_start
             self._phase['rebalance_calls'] += 1

@@ -195,6 +195,15 @@ class ModelEngine:
         section mark `section` (-1: never).  Raises with the shipped library."""
         check(self._lib.qmc_engine_section_cut(self._h, int(section)))
 
+    def general_path_walkers(self, reset: bool = True) -> int:
+        """Walker evaluations of the VMC / DMC stepping kernels that left the
+        sorted-row pair sums (33 <= N <= 128) for the general one inside the
+        same kernel since the last reset: 0 on equilibrated boxes, > 0 for
+        clustered walkers (a device counter on the cold path only)."""
+        out = (C.c_uint64 * 4)()
+        check(self._lib.qmc_engine_diag_counters(self._h, out, 4, int(reset)))
+        return int(out[0])
+
     def section_names(self):
         return [self._lib.qmc_section_name(i).decode() for i in range(16)]
 

@@ -32,11 +32,12 @@ class Backend:
         pass
 
     def sharded_population(self, n, start, cap, global_target, rank, world,
-                           equil, rebalance_every):
+                           equil, rebalance_every, solo=False):
         model = orc.model_from_cfc(box_spec(n).cfc_spec)
         rng = np.random.RandomState(100 + rank)
         pos = n * rng.random_sample((start, n))
         shard = OracleShard(orc, model, pos, 6.25e-4, cap, global_target, 0.5,
                             seed=1, slot0=rank << 26)
-        dd = DistributedDmc(shard, n, 'cpu', rebalance_every=rebalance_every)
+        dd = DistributedDmc(shard, n, 'cpu', rebalance_every=rebalance_every,
+                            solo=solo)
         return shard, dd, None, start

@@ -64,6 +64,20 @@ def test_bench_spawns_two_ranks(oracle):
     assert ph['allreduce_us_per_step_max_over_ranks'] > 0
     assert ph['host_enqueue_us_per_step_max_over_ranks'] > 0
     assert ph['rebalance_ms_total_max_over_ranks'] > 0
+    # both scaling curves under the same keys at every --gpus, and the 1-GPU
+    # strong-scaling reference measured in this run (rank 0 alone, the other
+    # rank at a barrier): a reader can draw the curve from the lines alone
+    assert set(ex['curves']) == {'vmc_n64_weak', 'dmc_n8_strong'}
+    assert ex['curves']['dmc_n8_strong'] == out['value']
+    assert ex['curves']['vmc_n64_weak'] is None     # (no VMC in the stand-in)
+    ss = ex['strong_scaling']
+    assert ss['curve'] == 'dmc_n8_strong' and ss['n_gpus'] == 2
+    assert ss['ref_1gpu'] > 0 and ss['value'] == out['value']
+    assert ss['speedup'] == pytest.approx(out['value'] / ss['ref_1gpu'])
+    assert ss['efficiency'] == pytest.approx(ss['speedup'] / 2)
+    assert 'same run' in ss['ref_measured']
+    assert 30 < ss['ref_detail']['mean_walkers'] < 70   # the WHOLE population
+    assert ex['weak_scaling'] is None
 
 
 def test_bench_refuses_world_size_mismatch():

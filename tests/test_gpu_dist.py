@@ -304,6 +304,19 @@ def test_bench_two_ranks_on_one_gpu_real_engine():
     # the weak-scaled VMC extra ran on both ranks as well
     assert ex['vmc_weak']['value'] > 0
     assert 15.0 < ex['vmc_weak']['energy_per_particle'] < 16.5
+    # both curves under the same keys, and their same-run 1-GPU references
+    # (rank 0 alone: the whole population of 16384 walkers / its 4096 chains)
+    assert ex['curves'] == {'vmc_n64_weak': ex['vmc_weak']['value'],
+                            'dmc_n128_strong': out['value']}
+    for key, curve in (('strong_scaling', 'dmc_n128_strong'),
+                       ('weak_scaling', 'vmc_n64_weak')):
+        sc = ex[key]
+        assert sc['curve'] == curve and sc['n_gpus'] == 2
+        assert sc['ref_1gpu'] > 0 and 'same run' in sc['ref_measured']
+        assert sc['efficiency'] == pytest.approx(
+            ex['curves'][curve] / sc['ref_1gpu'] / 2)
+    assert 0.9 * 16384 < ex['strong_scaling']['ref_detail']['mean_walkers'] \
+        < 1.1 * 16384
 
 
 def test_distributed_vmc_reduces_block_sums_on_the_device():

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 2e-11
 ALL_TAGS = ['box8', 'box16', 'box64', 'box128', 'box512', 'free16', 'deep100',
-            'deep16', 'ideal16', 'defect24', 'odd24']
+            'deep16', 'ideal16', 'defect24', 'odd24', 'box37', 'box48', 'box100',
+        'box126']
 
 
 def close(a, b, rtol=RTOL):
@@ -68,12 +69,16 @@ def test_evaluate_vs_reference_golden(engines, golden_kernels, tag):
                                        ('deep100', 40), ('defect24', 100),
                                        ('odd24', 100), ('free16', 100)])
 def test_evaluate_vs_oracle_random(engines, oracle, golden_params, tag, nconf):
-    """Seeded random configurations (including negative / beyond-box positions
-    is NOT done here: sampling keeps walkers inside [0, L))."""
+    """Seeded random configurations; every fourth one with particles up to
+    two box lengths outside [0, L) on either side (the reference's functions
+    are periodic through their minimum-image distances)."""
     m = oracle_model(oracle, golden_params, tag)
-    rng = np.random.RandomState(hash(tag) % 2**31)
+    rng = np.random.RandomState(sum(map(ord, tag)))
     L, n = m.supercell_size, m.boson_number
     pos = L * rng.random_sample((nconf, n))
+    shift = L * rng.randint(-2, 3, size=(nconf, n))
+    shift[np.arange(nconf) % 4 != 0] = 0
+    pos = pos + shift
     wf, en, ith, dr = oracle.evaluate_set(m, pos)
     out = engines(tag).evaluate(pos)
     assert close(out.wf_abs_log, wf), worst(out.wf_abs_log, wf)
@@ -189,8 +194,11 @@ def test_dmc_tape_replay_one_block(engines, golden_dmc_tape):
 def test_vmc_philox_matches_oracle(engines, oracle, golden_params):
     """Same seed, same counter RNG: device chains and oracle chains follow the
     same trajectories (Philox4x32-10 keyed by (seed; chain, step, particle,
-    stream) on both sides)."""
+    stream) on both sides).  A chain may leave the oracle only through a
+    Metropolis test whose margin is at rounding level, which is checked
+    (tests/_traj.py); observed here: 0 of 37 chains."""
     from phd_qmclib_amd.engine import VmcEnsemble
+    from ._traj import explain_flips
     tag, W, ns = 'box16', 37, 24
     m = oracle_model(oracle, golden_params, tag)
     rng = np.random.RandomState(17)
@@ -199,21 +207,19 @@ def test_vmc_philox_matches_oracle(engines, oracle, golden_params):
     ens.set_state(pos0)
     out = ens.run_block(ns, series=True)
     out2 = ens.run_block(ns, series=True)
-    n_match = 0
+    st_o, en_o, wf_o = [np.zeros((2 * ns, W)) for _ in range(3)]
     for c in range(W):
         ch = oracle.VmcChain(m, pos0[c], 0.125, seed=123456789, chain=c)
         wf, en, st, _ = ch.run(ns)
         wf2, en2, st2, _ = ch.run(ns)
-        ok = (np.array_equal(st, out['move_stat'][:, c]) and
-              np.array_equal(st2, out2['move_stat'][:, c]))
-        if ok:
-            n_match += 1
-            assert close(np.r_[en, en2], np.r_[out['energy'][:, c],
-                                               out2['energy'][:, c]], 1e-9)
-            assert close(np.r_[wf, wf2], np.r_[out['wf_abs_log'][:, c],
-                                               out2['wf_abs_log'][:, c]], 1e-9)
-    # a rounding-level difference may flip a marginal accept; nearly all match
-    assert n_match >= W - 1
+        st_o[:, c], en_o[:, c], wf_o[:, c] = np.r_[st, st2], np.r_[en, en2], \
+            np.r_[wf, wf2]
+    same = explain_flips(oracle, m, pos0, 0.125, 123456789,
+                         np.r_[out['move_stat'], out2['move_stat']], st_o)
+    assert close(en_o[:, same], np.r_[out['energy'], out2['energy']][:, same],
+                 1e-9)
+    assert close(wf_o[:, same],
+                 np.r_[out['wf_abs_log'], out2['wf_abs_log']][:, same], 1e-9)
     ens.close()
 
 
@@ -339,15 +345,16 @@ def test_trajectories_at_other_cutoffs(oracle, cutoff):
     ens = VmcEnsemble(eng, W, 0.125, rng_seed=99)
     ens.set_state(pos0)
     out = ens.run_block(ns, series=True)
-    n_match = 0
+    st_o, en_o, wf_o = [np.zeros((ns, W)) for _ in range(3)]
     for c in range(W):
-        wf, en, st, _ = oracle.VmcChain(m, pos0[c], 0.125, seed=99,
-                                        chain=c).run(ns)
-        if np.array_equal(st, out['move_stat'][:, c]):
-            n_match += 1
-            assert close(en, out['energy'][:, c], 1e-9)
-            assert close(wf, out['wf_abs_log'][:, c], 1e-9)
-    assert n_match >= W - 1
+        wf_o[:, c], en_o[:, c], st_o[:, c], _ = oracle.VmcChain(
+            m, pos0[c], 0.125, seed=99, chain=c).run(ns)
+    # (a chain may leave the oracle only through a rounding-level Metropolis
+    # margin, checked in tests/_traj.py; observed: none)
+    from ._traj import explain_flips
+    same = explain_flips(oracle, m, pos0, 0.125, 99, out['move_stat'], st_o)
+    assert close(en_o[:, same], out['energy'][:, same], 1e-9)
+    assert close(wf_o[:, same], out['wf_abs_log'][:, same], 1e-9)
     ens.close()
     d = DmcEnsemble(eng, 1e-3, 64, 48, 0.5, rng_seed=77)
     d.set_state(pos0)

@@ -1,0 +1,173 @@
+"""The sorted-row pair sums (csrc/qmc_sorted64.h, qmc_sorted128.h) -- the code
+that evaluates > 99.9 % of the walkers of the benchmarked and production steps
+at 33 <= N <= 128 -- on the REFERENCE's golden configurations (VERDICT r3,
+missing 1).  `qmc_evaluate` / `build_state` always take the general pair sum
+(`eval_walker`), so `test_evaluate_vs_reference_golden` never reaches them;
+here the golden configurations go through the stepping kernels themselves,
+through the C-ABI only:
+
+* VMC: each configuration is the initial state of a chain; the forced first
+  yield (qmc_base/vmc.py:616-618) evaluates log|psi| with the sorted log-psi
+  pass and the energy with the sorted energy pass of `vmc_step_kernel`;
+* DMC: the configurations are a population stepped twice under a tape of zero
+  normals with time_step = 1e-300: positions do not move (z + 2 F dt + 0 = z
+  to the bit), weights are exp(-1e-300 x) = 1, every walker has one child, and
+  what the second yield hands back -- energy and drift (confs[:, 1]) of the
+  first step's children -- was computed by the sorted energy + drift pass of
+  `dmc_evolve_kernel`.
+
+Reference functions pinned: qmc_base/jastrow/model.py:298-366 (wf_abs_log),
+:793-854 (ith_energy_and_drift, summed: energy / drift),
+mrbp_qmc/model.py:468-529 (two-body factor).  Tolerance: the suite's
+2e-11 max(1, |x|).  The device's counter of walkers that left the sorted path
+must stay 0: the values compared here did come from it."""
+import numpy as np
+import pytest
+
+from .test_gpu_parity import RTOL, close, spec_from_golden, worst
+
+pytestmark = pytest.mark.gpu
+
+# every golden spec on a sorted-row shape: exact N = 64 / 128, rings shorter
+# than the wavefront (N = 37 odd, 48), two particles per lane on N / 2 lanes
+# (100 with and without the deep lattice, 126: an odd number of lanes)
+TAGS = ['box64', 'box128', 'deep100', 'box37', 'box48', 'box100', 'box126']
+
+
+@pytest.fixture(scope='module')
+def engines(golden_params):
+    from phd_qmclib_amd.engine import ModelEngine
+    cache = {}
+
+    def get(tag):
+        if tag not in cache:
+            cache[tag] = ModelEngine(spec_from_golden(golden_params, tag).cfc_spec)
+        return cache[tag]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_vmc_first_yield_on_golden_configurations(engines, golden_kernels, tag):
+    from phd_qmclib_amd.engine import VmcEnsemble
+    eng = engines(tag)
+    pos = golden_kernels[tag + '/pos']
+    W = pos.shape[0]
+    eng.general_path_walkers(reset=True)
+    for series in (True, False):
+        v = VmcEnsemble(eng, W, 0.125, rng_seed=1)
+        v.set_state(pos)
+        out = v.run_block(1, series=series)
+        # (the block sums of a one-yield block ARE the first yield: the
+        # production kernel, LEAN = true, has no series)
+        en = out['energy'][0] if series else out['sum_energy']
+        ref = golden_kernels[tag + '/energy']
+        assert close(en, ref), (tag, 'energy', series, worst(en, ref))
+        assert np.all(out['num_accepted'] == 1)
+        p, wf, ec = v.get_state()
+        ref = golden_kernels[tag + '/wf_abs_log']
+        assert close(wf, ref), (tag, 'wf_abs_log', series, worst(wf, ref))
+        if series:
+            assert np.array_equal(out['wf_abs_log'][0], wf)
+            assert out['move_stat'].all()
+        assert np.array_equal(p, pos)           # the state is handed back as given
+        assert close(ec, golden_kernels[tag + '/energy'])
+        v.close()
+    assert eng.general_path_walkers() == 0, 'a golden row left the sorted path'
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_dmc_zero_move_step_on_golden_configurations(engines, golden_kernels,
+                                                     tag):
+    from phd_qmclib_amd.engine import DmcEnsemble
+    eng = engines(tag)
+    pos = golden_kernels[tag + '/pos']
+    W, n = pos.shape
+    L = float(eng.cfc_spec.model_params.supercell_size)
+    eng.general_path_walkers(reset=True)
+    d = DmcEnsemble(eng, 1e-300, W, W, 0.5, rng_seed=1)
+    d.set_state(pos)
+    d.set_tape(np.zeros(2 * W), np.zeros(2 * W * n), [0, W], [0, W * n])
+    ser = d.run_block(2)
+    assert np.array_equal(ser.num_walkers, [W, W])
+    st = d.get_state()
+    assert st.num_walkers == W
+    assert np.array_equal(st.cloning_ref[:W], np.arange(W))
+    # positions: unchanged (a particle at exactly 0 may come back as 2 F dt, or
+    # as L when its drift is negative -- the reference's floor-mod gives the
+    # same, qmc_base/utils.py:55-66)
+    dz = np.abs(st.confs[:W, 0] - pos)
+    assert np.all(np.minimum(dz, L - dz) <= 1e-250)
+    ref = golden_kernels[tag + '/energy']
+    assert close(st.energy[:W], ref), (tag, 'energy', worst(st.energy[:W], ref))
+    ref = golden_kernels[tag + '/ith_drift']
+    assert close(st.confs[:W, 1], ref), (tag, 'drift',
+                                         worst(st.confs[:W, 1], ref))
+    # E_t of the second yield = sum of those energies (unit weights)
+    assert close(ser.energy[1], golden_kernels[tag + '/energy'].sum(),
+                 rtol=RTOL * W)
+    assert np.array_equal(ser.weight, [W, W])
+    d.close()
+    assert eng.general_path_walkers() == 0, 'a golden row left the sorted path'
+
+
+@pytest.mark.parametrize('tag', ['box64', 'box128', 'odd24'])
+def test_out_of_box_initial_configuration(golden_params, golden_kernels, oracle,
+                                          tag):
+    """an initial configuration with particles outside [0, L).  The
+    reference takes `ini_sys_conf` as it comes: its pair distances are minimum
+    images (qmc_base/utils.py:35-51), its one-body factor takes z mod 1 of the
+    position as given (mrbp_qmc/model.py:417, 440) -- in the supercell of
+    'odd24', 17.5 lattice periods, a particle outside the box does not see what
+    its image inside sees -- and only proposals are recast
+    (mrbp_qmc/vmc.py:215-233).  The device evaluates such a first yield with
+    the general pair sum (pair tables from the images inside the box, one-body
+    factor from the positions as given; counted), hands the configuration back
+    as it was given until the first accepted move, and follows the oracle's
+    chain from there on the sorted-row path; the batch evaluation
+    (`qmc_evaluate`) and `build_state` of DMC accept such positions as well."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
+    from .conftest import oracle_model
+    eng = ModelEngine(spec_from_golden(golden_params, tag).cfc_spec)
+    m = oracle_model(oracle, golden_params, tag)
+    L = float(m.supercell_size)
+    pos = golden_kernels[tag + '/pos'][:4].copy()
+    pos[0, 3] += L             # one period up
+    pos[1, 5] -= L             # one period down
+    pos[2, :] += 2 * L         # the whole row two periods up
+    pos[3, 7] -= 3 * L         # three periods down
+    wf, en, ie, fd = oracle.evaluate_set(m, pos)
+    out = eng.evaluate(pos)
+    for got, ref in ((out.wf_abs_log, wf), (out.energy, en),
+                     (out.ith_energy, ie), (out.drift, fd)):
+        assert close(got, ref), worst(got, ref)
+    eng.general_path_walkers(reset=True)
+    v = VmcEnsemble(eng, 4, 0.125, rng_seed=9)
+    v.set_state(pos)
+    first = v.run_block(1, series=True, confs=True)
+    assert close(first['energy'][0], en) and close(first['wf_abs_log'][0], wf)
+    assert np.array_equal(first['pos'][0], pos)      # as given
+    assert np.array_equal(v.get_state()[0], pos)
+    sorted_shape = m.boson_number > 32
+    if sorted_shape:
+        assert eng.general_path_walkers() == 4       # the first yield only
+    out = v.run_block(6, series=True)
+    assert eng.general_path_walkers() == 0
+    for c in range(4):
+        ch = oracle.VmcChain(m, pos[c], 0.125, seed=9, chain=c)
+        ch.run(1)
+        wf_c, en_c, st_c, _ = ch.run(6)
+        assert np.array_equal(st_c, out['move_stat'][:, c])
+        assert close(en_c, out['energy'][:, c], 1e-9)
+        assert close(wf_c, out['wf_abs_log'][:, c], 1e-9)
+    v.close()
+    # DMC build_state (mrbp_qmc/dmc.py:268-328): energies and drifts of the
+    # configurations as given
+    d = DmcEnsemble(eng, 1e-3, 8, 4, 0.5, rng_seed=1)
+    d.set_state(pos)
+    st = d.get_state()
+    assert close(st.energy[:4], en) and close(st.confs[:4, 1], fd)
+    assert np.array_equal(st.confs[:4, 0], pos)
+    d.close()
+    eng.close()

@@ -9,7 +9,8 @@ import pytest
 from .conftest import GOLDEN, oracle_model
 
 TAGS = ['box8', 'box16', 'box64', 'box128', 'box512', 'free16', 'deep100',
-        'deep16', 'ideal16', 'defect24', 'odd24']
+        'deep16', 'ideal16', 'defect24', 'odd24', 'box37', 'box48', 'box100',
+        'box126']
 
 
 @pytest.mark.parametrize('tag', TAGS)

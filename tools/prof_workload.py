@@ -53,4 +53,6 @@ else:
         d.set_state(pos)
     d.run_block(a.steps, read=False)
     eng.sync()
+from phd_qmclib_amd import _lib  # noqa: E402
+print('kernel_source_sha=' + _lib.source_hash())
 print('done')

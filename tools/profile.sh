@@ -15,4 +15,6 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CO
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc3 -- python3 $R/tools/prof_workload.py "$@" > $out/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc4 -- python3 $R/tools/prof_workload.py "$@" > $out/pmc4.log 2>&1
 python3 $R/tools/pmc_summary.py $out ${PMC_LAST:+--last $PMC_LAST} > $out/summary.txt 2>&1
+# which kernels were measured (tools/make_traffic.py -> profiles/traffic.json)
+grep -h '^kernel_source_sha=' $out/pmc4.log | tail -1 >> $out/summary.txt
 cat $out/summary.txt
