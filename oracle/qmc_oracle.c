@@ -100,6 +100,62 @@ void orc_philox_uniform2(uint64_t seed, uint32_t slot, uint32_t step,
     u[1] = u53(c[2], c[3]);
 }
 
+/* Philox2x32-10 (same paper): one 64-bit block per call.  The uniform
+ * proposal of the VMC step draws from it -- a particle needs ONE number per
+ * step, and the device pays per instruction issued, not per lane served: the
+ * 4x32 generator computed 128 bits per lane to use 64 of them. */
+static void philox2x32_10(uint32_t c[2], uint32_t k)
+{
+    const uint32_t M = 0xD256D193u, W = 0x9E3779B9u;
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p = (uint64_t)M * c[0];
+        uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c[1];
+        c[1] = (uint32_t)p;
+        c[0] = n0;
+        k += W;
+    }
+}
+
+void orc_philox2x32(uint32_t c0, uint32_t c1, uint32_t key, uint32_t *out)
+{
+    uint32_t c[2] = { c0, c1 };
+    philox2x32_10(c, key);
+    out[0] = c[0];
+    out[1] = c[1];
+}
+
+/* The VMC move stream: (key; counter) of the block of particle `index` of
+ * chain `slot` at Metropolis step `step`.  Every (slot < 2^28, step < 2^26,
+ * index < 1024) has its own counter under the key of the seed; bits beyond
+ * those ranges move into the key (distinct blocks again, as far as 32 bits of
+ * key allow).  The 64-bit seed is folded into the 32-bit key. */
+void orc_vmc_move_block(uint64_t seed, uint32_t slot, uint32_t step,
+                        uint32_t index, uint32_t *w)
+{
+    uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    key += (step >> 26) * 0x632BE5ABu + (slot >> 28) * 0xC2B2AE35u;
+    uint32_t c[2];
+    c[0] = ((step & 0x3FFFFFFu) << 6) | ((slot >> 22) & 0x3Fu);
+    c[1] = ((slot & 0x3FFFFFu) << 10) | (index & 0x3FFu);
+    philox2x32_10(c, key);
+    w[0] = c[0];
+    w[1] = c[1];
+}
+
+/* word 0 -> the particle's displacement in units of the move spread,
+ * (w0 + 1/2) 2^-32 - 1/2 in (-1/2, 1/2): 32 random bits, every step exact */
+double orc_vmc_move_unit(uint32_t w0)
+{
+    return ((double)w0 + 0.5) * (1.0 / 4294967296.0) - 0.5;
+}
+
+/* the accept draw of a step: 53 bits from the second words of the blocks of
+ * particles 0 and 1 (of particle 0 twice in a one-particle model) */
+double orc_vmc_accept_uniform(uint32_t w1_p0, uint32_t w1_p1)
+{
+    return u53(w1_p0, w1_p1);
+}
+
 void orc_philox_normal2(uint64_t seed, uint32_t slot, uint32_t step,
                         uint32_t index, uint32_t stream, double *g)
 {
@@ -348,7 +404,7 @@ int64_t orc_vmc_chain(const orc_model *m, const orc_vmc_cfg *cfg,
             stat = 1;
         } else {
             /* qmc_base/jastrow/vmc.py:208-224 + mrbp_qmc/vmc.py:215-233 */
-            double ua_spare = 1.0;
+            uint32_t a_hi = 0, a_lo = 0;   /* words of the accept draw */
             for (int64_t i = 0; i < nop; ++i) {
                 double d;
                 if (tape) {
@@ -360,12 +416,13 @@ int64_t orc_vmc_chain(const orc_model *m, const orc_vmc_cfg *cfg,
                                        (uint32_t)i, ORC_STREAM_VMC_MOVE, g);
                     d = 0 + cfg->move_spread * g[0];
                 } else {
-                    double u[2];
-                    orc_philox_uniform2(cfg->seed, cfg->chain, step,
-                                        (uint32_t)i, ORC_STREAM_VMC_MOVE, u);
-                    d = (u[0] - 0.5) * cfg->move_spread;
-                    /* the accept draw is the spare double of particle 0 */
-                    if (i == 0) ua_spare = u[1];
+                    uint32_t w[2];
+                    orc_vmc_move_block(cfg->seed, cfg->chain, step,
+                                       (uint32_t)i, w);
+                    d = orc_vmc_move_unit(w[0]) * cfg->move_spread;
+                    /* the accept draw: second words of particles 0 and 1 */
+                    if (i == 0) a_hi = a_lo = w[1];
+                    if (i == 1) a_lo = w[1];
                 }
                 prop[i] = recast(pos[i] + d, 0., 1. * L);
             }
@@ -379,7 +436,7 @@ int64_t orc_vmc_chain(const orc_model *m, const orc_vmc_cfg *cfg,
                                     ORC_STREAM_VMC_ACCEPT, u);
                 ua = u[0];
             } else {
-                ua = ua_spare;
+                ua = orc_vmc_accept_uniform(a_hi, a_lo);
             }
             stat = 0;
             /* qmc_base/vmc.py:636 */

@@ -43,13 +43,24 @@ typedef struct {
 } orc_model;
 
 /* Counter RNG shared (as an algorithm) with the device engine: Philox4x32-10,
- * key = seed, counter = (slot, step, index, stream). */
+ * key = seed, counter = (slot, step, index, stream) -- DMC branching and
+ * diffusion, the Gaussian VMC proposal -- and Philox2x32-10 for the uniform
+ * VMC proposal (below). */
 enum { ORC_STREAM_VMC_MOVE = 0, ORC_STREAM_VMC_ACCEPT = 1,
        ORC_STREAM_DMC_BRANCH = 2, ORC_STREAM_DMC_DIFFUSE = 3 };
 void orc_philox_uniform2(uint64_t seed, uint32_t slot, uint32_t step,
                          uint32_t index, uint32_t stream, double *u);
 void orc_philox_normal2(uint64_t seed, uint32_t slot, uint32_t step,
                         uint32_t index, uint32_t stream, double *g);
+/* Philox2x32-10, one 64-bit block: the uniform proposal of the VMC step.
+ * orc_vmc_move_block: the block of (seed; chain slot, step, particle);
+ * word 0 -> displacement / move_spread = (w0 + 1/2) 2^-32 - 1/2; the accept
+ * draw of a step = u53(word 1 of particle 0, word 1 of particle 1). */
+void orc_philox2x32(uint32_t c0, uint32_t c1, uint32_t key, uint32_t *out);
+void orc_vmc_move_block(uint64_t seed, uint32_t slot, uint32_t step,
+                        uint32_t index, uint32_t *w);
+double orc_vmc_move_unit(uint32_t w0);
+double orc_vmc_accept_uniform(uint32_t w1_p0, uint32_t w1_p1);
 /* DMC diffusion normal: steps 2m / 2m+1 share one block (cos / sin branch) */
 double orc_philox_normal(uint64_t seed, uint32_t slot, uint32_t step,
                          uint32_t index, uint32_t stream);

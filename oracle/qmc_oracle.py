@@ -151,6 +151,16 @@ def lib():
         L.orc_philox_normal.restype = C.c_double
         L.orc_philox_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_uint32]
+        _u32p = C.POINTER(C.c_uint32)
+        L.orc_philox2x32.restype = None
+        L.orc_philox2x32.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
+        L.orc_vmc_move_block.restype = None
+        L.orc_vmc_move_block.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, _u32p]
+        L.orc_vmc_move_unit.restype = C.c_double
+        L.orc_vmc_move_unit.argtypes = [C.c_uint32]
+        L.orc_vmc_accept_uniform.restype = C.c_double
+        L.orc_vmc_accept_uniform.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -225,6 +235,30 @@ def philox_uniform2(seed, slot, step, index, stream):
     u = np.zeros(2)
     lib().orc_philox_uniform2(seed, slot, step, index, stream, _p(u))
     return u
+
+
+def philox2x32(c0, c1, key):
+    """Philox2x32-10 block of counter (c0, c1) under `key` -> (w0, w1)."""
+    w = (C.c_uint32 * 2)()
+    lib().orc_philox2x32(c0, c1, key, w)
+    return int(w[0]), int(w[1])
+
+
+def vmc_move_block(seed, slot, step, index):
+    """The VMC move stream's block of (seed; chain slot, step, particle)
+    -> (w0, w1)."""
+    w = (C.c_uint32 * 2)()
+    lib().orc_vmc_move_block(seed, slot, step, index, w)
+    return int(w[0]), int(w[1])
+
+
+def vmc_move_unit(w0):
+    """displacement / move_spread of a particle from word 0 of its block"""
+    return float(lib().orc_vmc_move_unit(w0))
+
+
+def vmc_accept_uniform(w1_p0, w1_p1):
+    return float(lib().orc_vmc_accept_uniform(w1_p0, w1_p1))
 
 
 def philox_normal(seed, slot, step, index, stream):

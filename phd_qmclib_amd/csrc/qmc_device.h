@@ -238,6 +238,48 @@ __device__ __forceinline__ void philox_uniform2(uint64_t seed, uint32_t slot,
     u1 = u53(c[2], c[3]);
 }
 
+// Philox2x32-10 (same paper): one 64-bit block per call.  The uniform proposal
+// of the VMC step draws from it: a particle needs ONE number per step and a
+// wavefront pays per instruction issued, not per lane served -- the 4x32
+// generator computed 128 bits per lane to use 64 of them (18 wide multiplies
+// and 34 xors per chain-step against 10 and 20 here).
+__device__ __forceinline__ void philox2x32_10(uint32_t &c0, uint32_t &c1,
+                                              uint32_t k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        const uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
+    }
+}
+
+// The VMC move stream (same definition in oracle/qmc_oracle.c:
+// orc_vmc_move_block): block of particle `index` of chain `slot` at Metropolis
+// step `step`.  Every (slot < 2^28, step < 2^26, index < 1024) has its own
+// counter under the key of the seed; bits beyond those ranges move into the
+// key.  Word 0 moves the particle -- (w0 + 1/2) 2^-32 - 1/2 times the move
+// spread, exact in double -- and the second words of the blocks of particles 0
+// and 1 make the step's accept draw (53 bits).
+__device__ __forceinline__ void vmc_move_block(uint64_t seed, uint32_t slot,
+                                               uint32_t step, uint32_t index,
+                                               uint32_t &w0, uint32_t &w1)
+{
+    uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    key += (step >> 26) * 0x632BE5ABu + (slot >> 28) * 0xC2B2AE35u;
+    w0 = ((step & 0x3FFFFFFu) << 6) | ((slot >> 22) & 0x3Fu);
+    w1 = ((slot & 0x3FFFFFu) << 10) | (index & 0x3FFu);
+    philox2x32_10(w0, w1, key);
+}
+
+__device__ __forceinline__ double vmc_move_unit(uint32_t w0)
+{
+    // (one conversion and one fused multiply-add: 2^-33 - 1/2 is exact)
+    return fma((double)w0, 0x1p-32, 0x1p-33 - 0.5);
+}
+
 // Box-Muller pair from one Philox block: both standard normals.
 __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t slot,
                                                uint32_t step, uint32_t index,

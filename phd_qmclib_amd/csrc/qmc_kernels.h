@@ -286,8 +286,11 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
     QMC_SECTION("load+philox+wrap");
     double zn[P];
     int labn[P];              // original particle index held by each lane
-    double ua = 1.0;          // accept uniform (particle 0's spare double)
-    double mine = -1.0;       // >= 0 only in the lane that holds particle 0
+    double ua = 1.0;          // accept uniform
+    // second words of the move blocks of particles 0 and 1 (the accept draw),
+    // in the lanes that hold those particles
+    unsigned int aw0 = 0u, aw1 = 0u;
+    bool has0 = false, has1 = false;
     bool outside = false;     // forced yield: a particle given outside [0, L)
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -307,12 +310,11 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
                                g1);
                 d = a.move_spread * g0;
             } else {
-                double u0, u1;
-                philox_uniform2(a.seed, slot, a.step, li, STREAM_VMC_MOVE, u0,
-                                u1);
-                d = (u0 - 0.5) * a.move_spread;
-                // the accept draw is the spare double of particle 0
-                mine = (li == 0u) ? u1 : mine;
+                uint32_t w0, w1;
+                vmc_move_block(a.seed, slot, a.step, li, w0, w1);
+                d = vmc_move_unit(w0) * a.move_spread;
+                if (li == 0u) { aw0 = w1; has0 = true; }
+                if (li == 1u || n == 1) { aw1 = w1; has1 = true; }
             }
         }
         // mrbp_qmc/vmc.py:215-233 (recast to the supercell).  The forced
@@ -407,23 +409,29 @@ vmc_step_kernel(const DevModel *__restrict__ mp, VmcArgs a)
             philox_uniform2(a.seed, slot, a.step, 0u, STREAM_VMC_ACCEPT, ua,
                             u1);
         } else {
-            // exactly one lane of the group holds particle 0 (ua >= 0 there):
-            // find it with a ballot and read its value
-            const unsigned long long bal = __ballot(mine >= 0.0);
+            // exactly one lane of the group holds particle 0 and one particle 1:
+            // find them with a ballot each and read their words
+            const unsigned long long bal0 = __ballot(has0);
+            const unsigned long long bal1 = __ballot(has1);
+            unsigned int hi, lo;
             if (G == 64) {
-                const int src = __builtin_amdgcn_readfirstlane(
-                    (int)__ffsll((long long)bal) - 1) & 63;
-                int lo = __double2loint(mine), hi = __double2hiint(mine);
-                lo = __builtin_amdgcn_readlane(lo, src);
-                hi = __builtin_amdgcn_readlane(hi, src);
-                ua = __hiloint2double(hi, lo);
+                const int src0 = __builtin_amdgcn_readfirstlane(
+                    (int)__ffsll((long long)bal0) - 1) & 63;
+                const int src1 = __builtin_amdgcn_readfirstlane(
+                    (int)__ffsll((long long)bal1) - 1) & 63;
+                hi = (unsigned)__builtin_amdgcn_readlane((int)aw0, src0);
+                lo = (unsigned)__builtin_amdgcn_readlane((int)aw1, src1);
             } else {
                 const int base = (threadIdx.x & 63) - gl;
-                const unsigned long long grp_bits =
-                    (bal >> base) & ((1ull << (G & 63)) - 1ull);
-                const int src = base + ((__ffsll((long long)grp_bits) - 1) & (G - 1));
-                ua = __shfl(mine, src, 64);
+                const unsigned long long gmask = (1ull << (G & 63)) - 1ull;
+                const int src0 = base + ((__ffsll((long long)((bal0 >> base) &
+                                                              gmask)) - 1) & (G - 1));
+                const int src1 = base + ((__ffsll((long long)((bal1 >> base) &
+                                                              gmask)) - 1) & (G - 1));
+                hi = (unsigned)__shfl((int)aw0, src0, 64);
+                lo = (unsigned)__shfl((int)aw1, src1, 64);
             }
+            ua = u53(hi, lo);
         }
     }
     if (!active) return;

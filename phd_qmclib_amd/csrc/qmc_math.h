@@ -164,14 +164,20 @@ __device__ __forceinline__ double exp_bounded(double x)
     return ldexp(p, (int)n);
 }
 
-// log(x) for normal positive x: x = m 2^k with m in [sqrt(1/2), sqrt(2)) (no
-// cancellation between k ln 2 and log m around x = 1); log m = L_r + log1p(d),
-// d = m inv_c_r - 1, from a 256-row table of {inv_c, L = -log(inv_c)} (row centre
-// c, inv_c the double nearest 1/c, L computed from that double: the identity is
-// exact) and five terms of log1p (|d| <= 1.95e-3: the sixth is 1e-17).  19
-// instructions, no division, against 30 + v_rcp_f64 for the atanh series this
-// replaces; worst deviation from long-double log 1.1e-16 (1 + |log x|)
-// (qmc_log_table_info, tests/test_cabi.py).
+// log(x) for normal positive x: x = m 2^k with m in [1/2, 1) as
+// v_frexp_mant_f64 / v_frexp_exp_i32_f64 deliver them; log m = L_r + log1p(d),
+// d = m inv_c_r - 1, from a 256-row table of {inv_c, L = -log(inv_c)} (row
+// centre c, inv_c the double nearest 1/c, L computed from that double: the
+// identity is exact) and five terms of log1p (|d| <= 1.95e-3: the sixth is
+// 1e-17).  16 instructions, no division, against 30 + v_rcp_f64 for the atanh
+// series this replaced.  Just above x = 1 (m just above 1/2, k = 1) the result
+// is the difference of k ln 2 and log m: its ABSOLUTE error stays at the
+// 1e-16 of those terms, which is what the callers need -- they sum logarithms
+// of pair products into log|psi| ~ 10^2..10^3 -- and what the bound states:
+// worst deviation from long-double log 1.25e-16 (1 + |log x|)
+// (qmc_log_table_info, tests/test_cabi.py).  (Round 3 moved the mantissa to
+// [sqrt(1/2), sqrt(2)) to keep the RELATIVE error near 1 as well: four
+// instructions per logarithm for a property nobody uses.)
 #ifndef QMC_LOG_TABLE
 #define QMC_LOG_TABLE 1
 #endif
@@ -206,11 +212,13 @@ __device__ __forceinline__ double log_pos(double x)
     if (!QMC_LOG_TABLE) return log_series(x);
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
-    // k = floor(log2(x sqrt 2)): m = x / 2^k in [sqrt(1/2), sqrt(2))
-    const int nk = 1 - __builtin_amdgcn_frexp_exp(x * 1.41421356237309504880);
-    const double m = ldexp(x, nk);
-    int r = (int)((m - QMC_LOG_LO) * QMC_LOG_INVW);
-    r = min(max(r, 0), QMC_LOG_ROWS - 1);    // (a last-bit excursion of m)
+    const double m = __builtin_amdgcn_frexp_mant(x);       // [1/2, 1)
+    const int k = __builtin_amdgcn_frexp_exp(x);
+    // row: truncation of (m - 1/2) 2 ROWS, in [0, ROWS) for every m
+    // (masked: an argument that is not a positive normal number -- never one
+    // whose result is used -- still reads inside the table)
+    const int r = (int)fma(m, (double)(2 * QMC_LOG_ROWS), -(double)QMC_LOG_ROWS) &
+                  (QMC_LOG_ROWS - 1);
     typedef const __attribute__((address_space(1))) double *gptr;
     const gptr row = (gptr)QMC_LOG_TAB + 2u * (unsigned)r;
     const double inv_c = row[0], L = row[1];
@@ -219,8 +227,8 @@ __device__ __forceinline__ double log_pos(double x)
     q = fma(q, d, sconst(1.0 / 3.0));
     q = fma(q, d, -0.5);
     const double lm = fma(d * d, q, d) + L;
-    const double kd = (double)nk;            // = -k
-    return fma(-kd, LN2_HI, fma(-kd, LN2_LO, lm));
+    const double kd = (double)k;
+    return fma(kd, LN2_HI, fma(kd, LN2_LO, lm));
 }
 
 __device__ __forceinline__ double fast_sqrt(double x)

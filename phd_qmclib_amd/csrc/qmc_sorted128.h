@@ -46,11 +46,12 @@ __device__ __forceinline__ typename SlotPair<R>::type ld_pair(const R *p)
 __device__ __forceinline__ bool rows_ascending128(const double (&z)[2],
                                                   int nl = 64)
 {
-    // lane i takes the next lane's first slot (the last lane keeps its own)
+    // lane i takes the next lane's first slot (the last lane 0.0, unused:
+    // bound_ctrl saves the copy of the old value)
     const int lo = __double2loint(z[0]), hi = __double2hiint(z[0]);
     const double up = __hiloint2double(
-        __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false),
-        __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false));
+        __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true),
+        __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true));
     const int lane = threadIdx.x & 63;
     const bool bad = (lane < nl) &
                      ((z[1] < z[0]) | ((lane < nl - 1) & (up < z[1])));
@@ -132,6 +133,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
 {
     constexpr int G = 64, NS = 128, H = SortedRows<NS>::H,
                   ROW = SortedRows<NS>::ROW;
+    constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;   // (qmc_sorted64.h)
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     const int n = PAD ? m.n : NS;            // particles (even)
@@ -164,8 +166,14 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         QMC_S128_ST(lCU, up, ta[0].cu, ta[1].cu);
         QMC_S128_ST(lZ, up, z[0], z[1]);
         if (lo >= 2) {
-            QMC_S128_ST(lS, lo, -ta[0].s, -ta[1].s);
-            QMC_S128_ST(lC, lo, -ta[0].c, -ta[1].c);
+            // (COT: ta.s = cot, the same one period below; ta.c = position)
+            if (COT) {
+                QMC_S128_ST(lS, lo, ta[0].s, ta[1].s);
+                QMC_S128_ST(lC, lo, z[0] - m.L, z[1] - m.L);
+            } else {
+                QMC_S128_ST(lS, lo, -ta[0].s, -ta[1].s);
+                QMC_S128_ST(lC, lo, -ta[0].c, -ta[1].c);
+            }
             QMC_S128_ST(lSU, lo,
                         fma(ta[0].su, m.cth, -(ta[0].cu * m.sth_signed)),
                         fma(ta[1].su, m.cth, -(ta[1].cu * m.sth_signed)));
@@ -225,11 +233,15 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     // lane, an LDS instruction costs the same for one lane as for 64, and a
     // read inside the exec-masked region is a lane-stride-16 access (2-way
     // bank conflict) whose latency nothing hides; 0: read where it is used)
+    // (COT, qmc_sorted64.h: cs = the partner's cotangent, cc = its position)
 #define QMC_S128_XY(oa, cs, cc, bsu, bcu, X, Y, sh)                           \
-    const R Y##_s = (oa).s * (cc) - (oa).c * (cs);   /* sin(pi D' / L) >= 0 */ \
+    const R Y##_s = COT ? (cs) - (oa).s              /* t_j - t_i */           \
+                        : (oa).s * (cc) - (oa).c * (cs);  /* sin(pi D'/L) >= 0 */ \
     R X = 0;                                                                  \
-    if (EN) X = (oa).c * (cc) + (oa).s * (cs);       /* cos(pi D' / L) */      \
-    const bool sh = q_abs(Y##_s) < sin_rm;           /* D' < rm */             \
+    if (EN) X = COT ? q_fma((oa).s, (cs), (R)1)      /* t_i t_j + 1 */         \
+                    : (oa).c * (cc) + (oa).s * (cs); /* cos(pi D' / L) */      \
+    const bool sh = COT ? (cc) > (oa).zt             /* D' < rm */             \
+                        : q_abs(Y##_s) < sin_rm;                              \
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \
         asm volatile("");                                                     \
@@ -241,6 +253,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     // ---- k = 0: the pair inside the lane (slot 1 against slot 0) ----
     QMC_SECTION("pairs_in_lane");
     {
+        // (COT: o.s is the cotangent and o.c the position, sorted_particle_setup)
         const R cs = (R)o[0].s, cc = (R)o[0].c;
         QMC_S128_XY(o[1], cs, cc, pSU[0], pCU[0], X, Y, sh)
         // (the products of an idle lane never reach the sums: its log is dropped)
@@ -369,18 +382,21 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     }
     // ... and of a step whose four pairs are long-range for every lane: no
     // classification, no exec-masked region
+#define QMC_S128_LONG_XY(oa, cs, cc, X, Y)                                    \
+    const R Y = COT ? (cs) - (oa).s : (oa).s * (cc) - (oa).c * (cs);          \
+    R X = 0;                                                                  \
+    if (EN) X = COT ? q_fma((oa).s, (cs), (R)1)                               \
+                    : (oa).c * (cc) + (oa).s * (cs);
 #define QMC_S128_LONG_STEP(s0_, c0_, s1_, c1_)                                \
     {                                                                         \
-        const R Y00 = o[0].s * (c0_) - o[0].c * (s0_);                        \
-        const R Y10 = o[1].s * (c0_) - o[1].c * (s0_);                        \
-        const R Y01 = o[0].s * (c1_) - o[0].c * (s1_);                        \
-        const R Y11 = o[1].s * (c1_) - o[1].c * (s1_);                        \
+        QMC_S128_LONG_XY(o[0], s0_, c0_, X00, Y00)                            \
+        QMC_S128_LONG_XY(o[1], s0_, c0_, X10, Y10)                            \
+        QMC_S128_LONG_XY(o[0], s1_, c1_, X01, Y01)                            \
+        QMC_S128_LONG_XY(o[1], s1_, c1_, X11, Y11)                            \
         if (WF && live) PL *= (Y00 * Y10) * (Y01 * Y11);                      \
         if (EN) {                                                             \
-            const R q00 = pair_div(o[0].c * (c0_) + o[0].s * (s0_), Y00);   \
-            const R q10 = pair_div(o[1].c * (c0_) + o[1].s * (s0_), Y10);   \
-            const R q01 = pair_div(o[0].c * (c1_) + o[0].s * (s1_), Y01);   \
-            const R q11 = pair_div(o[1].c * (c1_) + o[1].s * (s1_), Y11);   \
+            const R q00 = pair_div(X00, Y00), q10 = pair_div(X10, Y10);       \
+            const R q01 = pair_div(X01, Y01), q11 = pair_div(X11, Y11);       \
             Fr[0] += q00 + q01;                                               \
             Fr[1] += q10 + q11;                                               \
             T[0] -= q00 + q10;                                                \
@@ -440,6 +456,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
 #undef QMC_S128_SU
 #undef QMC_S128_CU
 #undef QMC_S128_LONG_STEP
+#undef QMC_S128_LONG_XY
 #undef QMC_S128_XY
 #undef QMC_S128_SHORT_XY
     if (EN) {

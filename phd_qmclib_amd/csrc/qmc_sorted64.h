@@ -47,14 +47,40 @@
 #ifndef QMC_T_LDS
 #define QMC_T_LDS 0
 #endif
+// Long-range pairs of the energy-only evaluation (the DMC step: no log|psi|)
+// from ONE table per particle, t = cot(pi z / L):
+//   a_long cot(pi D' / L) = a_long (t_i t_j + 1) / (t_j - t_i),
+// numerator and denominator in one instruction each instead of two (mul + fma)
+// from the sin / cos tables -- two fp64 operations fewer per long pair, and the
+// round-4 micro-benchmark (tools/ubench5.hip) says it is fp64 operations, not
+// issue slots, that the chip's power budget pays for.  The pair class comes
+// from the positions (partner above z - rm: the test the leading steps use)
+// instead of from the sine, so the partner's second table entry is its position
+// -- the same two LDS reads per general step.  cot is periodic in L, so the copy
+// "one period below" is the same number; at z -> 0 it diverges: sin is clamped
+// from below (a particle closer than 1e-290 to the seam), which changes a long
+// pair's quotient by 1e-280 of itself, and a pair of two such particles is
+// never long.  Accuracy otherwise that of the two-table form (the quotient of
+// two correctly rounded operations on correctly rounded cotangents).
+// The log|psi| pass needs sin(pi D' / L) itself (the factor of the product),
+// so the VMC step keeps the sin / cos tables.
+#ifndef QMC_COT
+#define QMC_COT 1
+#endif
+template <bool WF, bool EN, bool REUSE>
+struct SortedCot {
+    static constexpr bool ON = QMC_COT && EN && !WF && !REUSE;
+};
 
-// lane i takes the value of lane i - 1 (lane 0 keeps its own)
+// lane i takes the value of lane i - 1, lane 0 takes 0.0 (bound_ctrl: no
+// copy of the old value first -- one v_mov_b32_dpp per word instead of two
+// instructions; positions are >= 0, so lane 0 never reads as "below")
 __device__ __forceinline__ double wave_shr1_f64(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     return __hiloint2double(
-        __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false),
-        __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false));
+        __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true),
+        __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true));
 }
 
 // lanes (of the first nl) whose particle lies BELOW the particle of the lane
@@ -267,6 +293,14 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         sincos_halfpi(z * m.two_over_L, ta.s, ta.c);
         sincos_halfpi(z * m.k2_2pi, ta.su, ta.cu);
     }
+    constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
+    if (COT) {
+        // (s >= 0 inside the box; float pair loop: 1e25 times a long partner's
+        // cotangent stays inside float)
+        const double tiny = sizeof(R) == 4 ? 1e-25 : 1e-290;
+        ta.s = fast_div(ta.c, fmax(ta.s, tiny));     // cot(pi z / L)
+        ta.c = z;                                     // second entry: position
+    }
     o.s = (R)ta.s; o.c = (R)ta.c;
     const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
     const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
@@ -284,7 +318,9 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         // of the row find when they look past slot 0
         const int lo = H + slot - n;
         if (lo >= 1) {
-            lS[lo] = (R)-ta.s; lC[lo] = (R)-ta.c;
+            // (cot: the same number one period below; its position is lZ's)
+            lS[lo] = COT ? (R)ta.s : (R)-ta.s;
+            lC[lo] = COT ? (R)(z - m.L) : (R)-ta.c;
             lSU[lo] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
             lCU[lo] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
             lZ[lo] = (R)(z - m.L);
@@ -307,6 +343,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                                               double &logwf)
 {
     constexpr int G = 64, H = SortedRows<G>::H, ROW = SortedRows<G>::ROW;
+    constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
       *lZ = lS + 4 * ROW;
     // sixth row (double whatever R is): the sums the partners collect
@@ -440,12 +477,16 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     // ---- general steps: classified pair by pair ----
     QMC_SECTION("rotation_loop_body");
     // numerator / denominator / class of a general step
+    // (COT: cs = the partner's cotangent, cc = its position)
 #define QMC_S64_XY(cs, cc, kk, LAST, X, Y, sh, mine)                          \
-    const R Y##_s = o.s * (cc) - o.c * (cs);   /* sin(pi D' / L) >= 0 */       \
+    const R Y##_s = COT ? (cs) - o.s           /* t_j - t_i */                 \
+                        : o.s * (cc) - o.c * (cs);  /* sin(pi D' / L) >= 0 */  \
     R X = 0;                                                                  \
-    if (EN) X = o.c * (cc) + o.s * (cs);       /* cos(pi D' / L) */            \
+    if (EN) X = COT ? q_fma(o.s, (cs), (R)1)   /* t_i t_j + 1 */               \
+                    : o.c * (cc) + o.s * (cs); /* cos(pi D' / L) */            \
     const bool mine = live & (!(LAST) || gl < K);                             \
-    const bool sh = q_abs(Y##_s) < sin_rm;     /* D' < rm */                   \
+    const bool sh = COT ? (cc) > o.zt          /* D' < rm */                   \
+                        : q_abs(Y##_s) < sin_rm;                              \
     if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));           \
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \

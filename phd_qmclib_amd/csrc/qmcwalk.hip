@@ -739,20 +739,17 @@ static double log_pos_host(double x)
 {
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
-    int fe;
-    frexp(x * 1.41421356237309504880, &fe);
-    const int nk = 1 - fe;
-    const double m = ldexp(x, nk);
-    int r = (int)((m - QMC_LOG_LO) * QMC_LOG_INVW);
-    r = r < 0 ? 0 : (r > QMC_LOG_ROWS - 1 ? QMC_LOG_ROWS - 1 : r);
+    int k;
+    const double m = frexp(x, &k);                         // [1/2, 1)
+    const int r = (int)fma(m, (double)(2 * QMC_LOG_ROWS), -(double)QMC_LOG_ROWS);
     const double inv_c = g_log_tab_host[2 * r], L = g_log_tab_host[2 * r + 1];
     const double d = fma(m, inv_c, -1.0);
     double q = fma(d, 0.2, -0.25);
     q = fma(q, d, 1.0 / 3.0);
     q = fma(q, d, -0.5);
     const double lm = fma(d * d, q, d) + L;
-    const double kd = (double)nk;
-    return fma(-kd, LN2_HI, fma(-kd, LN2_LO, lm));
+    const double kd = (double)k;
+    return fma(kd, LN2_HI, fma(kd, LN2_LO, lm));
 }
 
 extern "C" int qmc_log_table_info(int32_t *rows, double *max_err)

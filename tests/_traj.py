@@ -29,18 +29,20 @@ def vmc_margin(oracle, m, pos0, spread, seed, chain, t):
     """The oracle's Metropolis margin log psi' - (0.5 ln u + log psi) at yield
     `t` (t >= 1; yield 0 is the initial state) of the chain started at pos0:
     the chain is replayed to yield t - 1, the proposal of the next step is
-    rebuilt from the shared Philox stream (STREAM_VMC_MOVE = 0: u0 moves
-    particle i, particle 0's u1 is the accept draw)."""
+    rebuilt from the shared Philox2x32 move stream (word 0 of particle i's
+    block moves it, the second words of particles 0 and 1 are the accept
+    draw: oracle/qmc_oracle.c, orc_vmc_move_block)."""
     assert t >= 1
     ch = oracle.VmcChain(m, pos0, spread, seed=seed, chain=chain)
     ch.run(t)
     step = int(ch.cfg.step0)
     n, L = int(m.boson_number), float(m.supercell_size)
-    u = np.array([oracle.philox_uniform2(seed, chain, step, i, 0)
-                  for i in range(n)])
-    prop = np.mod(ch.pos + (u[:, 0] - 0.5) * spread, L)
+    w = [oracle.vmc_move_block(seed, chain, step, i) for i in range(n)]
+    d = np.array([oracle.vmc_move_unit(w0) for w0, _ in w]) * spread
+    prop = np.mod(ch.pos + d, L)
     wf_new = oracle.wf_abs_log(m, prop)
-    return float(wf_new - (0.5 * np.log(u[0, 1]) + ch.wf[0]))
+    ua = oracle.vmc_accept_uniform(w[0][1], w[min(1, n - 1)][1])
+    return float(wf_new - (0.5 * np.log(ua) + ch.wf[0]))
 
 
 def explain_flips(oracle, m, pos0, spread, seed, stat_dev, stat_orc,

@@ -120,6 +120,44 @@ def test_philox_known_answer(oracle):
     assert u[1] == u53(0xa20bc7c6, 0x6d5451fd)
 
 
+def test_philox2x32_known_answer(oracle):
+    """Random123 known-answer vectors for Philox2x32-10 (kat_vectors:
+    counter, key -> block), the generator of the VMC move stream, and the
+    stream's keying: distinct counters for distinct (chain, step, particle),
+    the exact displacement / accept-draw arithmetic."""
+    assert oracle.philox2x32(0, 0, 0) == (0xff1dae59, 0x6cd10df2)
+    assert oracle.philox2x32(0xffffffff, 0xffffffff, 0xffffffff) == \
+        (0x2c3f628b, 0xab4fd7ad)
+    assert oracle.philox2x32(0x243f6a88, 0x85a308d3, 0x13198a2e) == \
+        (0xdd7ce038, 0xf62a4c12)
+    # keying (oracle/qmc_oracle.c: orc_vmc_move_block)
+    seed = 0x0123456789abcdef
+    key = ((seed & 0xffffffff) ^ ((seed >> 32) * 0x85EBCA6B)) & 0xffffffff
+    slot, step, idx = 0x2345678, 0x1abcdef, 0x2a5
+    c0 = ((step & 0x3ffffff) << 6) | ((slot >> 22) & 0x3f)
+    c1 = ((slot & 0x3fffff) << 10) | idx
+    assert oracle.vmc_move_block(seed, slot, step, idx) == \
+        oracle.philox2x32(c0, c1, key)
+    seen = set()
+    for sl in (0, 1, (1 << 22) - 1, 1 << 22, (1 << 28) - 1):
+        for st in (0, 1, (1 << 26) - 1):
+            for i in (0, 1, 511, 1023):
+                seen.add(oracle.vmc_move_block(7, sl, st, i))
+    assert len(seen) == 5 * 3 * 4
+    # bits beyond the counter's ranges move into the key
+    assert oracle.vmc_move_block(7, 1 << 28, 0, 0) != \
+        oracle.vmc_move_block(7, 0, 0, 0)
+    assert oracle.vmc_move_block(7, 0, 1 << 26, 0) != \
+        oracle.vmc_move_block(7, 0, 0, 0)
+    assert oracle.vmc_move_unit(0) == 2.0 ** -33 - 0.5
+    assert oracle.vmc_move_unit(0xffffffff) == 0.5 - 2.0 ** -33
+    assert oracle.vmc_move_unit(0x80000000) == 2.0 ** -33
+    assert oracle.vmc_accept_uniform(0xffffffff, 0xffffffff) == \
+        1.0 - 2.0 ** -53
+    assert oracle.vmc_accept_uniform(0x12345678, 0x9abcdef0) == float(
+        ((0x12345678 >> 5) << 26) | (0x9abcdef0 >> 6)) / 2.0 ** 53
+
+
 def test_vmc_ndf_tape_replay(oracle, golden_params):
     """Gaussian-proposal VMC (qmc_base/vmc_ndf.py:43-59, mrbp_qmc/vmc_ndf.py):
     the oracle's chain on the reference's recorded normal()/rand() streams --
