@@ -371,6 +371,11 @@ def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False):
         return k
 
     run_steps(args.warmup)
+    # (device counter of walkers that leave the sorted-row pair sums: read
+    # over the timed region -- which code did the timed kernel run?)
+    gp = getattr(eng, 'general_path_walkers', None)
+    if gp is not None:
+        gp(reset=True)
     barrier()
     eng.timer_start()
     t0 = time.perf_counter()
@@ -378,6 +383,7 @@ def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False):
     kernel_ms = eng.timer_stop()          # HIP events on the launch stream
     barrier()
     dt = time.perf_counter() - t0
+    gp_timed = None if gp is None else int(gp(reset=True))
     if use_pg:
         tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -396,7 +402,7 @@ def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False):
         dist.all_reduce(tot)
     tot = tot.cpu().numpy()
     return dict(vmc=vmc, eng=eng, dt=dt, kernel_ms=kernel_ms,
-                launches=launches,
+                launches=launches, general_path_walkers=gp_timed,
                 launch_ms_avg_isolated=tot_ms / max(nl, 1),
                 launch_ms_min=min_ms, launch_ms_max=max_ms,
                 energy_per_particle=float(tot[0] / tot[2] / n),
@@ -827,16 +833,6 @@ def scaling_entry(curve, value, ref, world, how, detail):
     return out
 
 
-def general_path_count(be, n):
-    """Walker evaluations of the engine's stepping kernels that left the
-    sorted-row pair sums for the general one since the engine was created
-    (equilibration included; a device counter): evidence of which code the
-    timed kernel ran."""
-    eng = be.engine(n)
-    f = getattr(eng, 'general_path_walkers', None)
-    return None if f is None else int(f(reset=False))
-
-
 # ------------------------------------------------------------------- main ---
 def run_rank(args):
     # stdout carries ONE JSON line and nothing else: libraries that print to
@@ -881,7 +877,9 @@ def run_rank(args):
         check_window('VMC acceptance', m['accept_rate'], VMC_ACC_WINDOW, args)
         out = vmc_line(args, m, n, W, world)
         curves[key_v] = ref_v = out['value']
-        out['extra']['general_path_walkers'] = general_path_count(be, n)
+        # walkers of the timed region evaluated by the general pair sum
+        # instead of the sorted-row one (of W x steps evaluations)
+        out['extra']['general_path_walkers_timed'] = m['general_path_walkers']
         if not args.no_dmc:
             out['extra']['dmc'] = bench_dmc_single(be, args, n, m['vmc'],
                                                    args.dmc_walkers)

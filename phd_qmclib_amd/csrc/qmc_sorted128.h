@@ -160,16 +160,16 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         const int up = H + 2 * gl, lo = up - n;
 #define QMC_S128_ST(row, i, v0, v1)                                           \
         *(R2 *)((row) + (i)) = R2{ (R)(v0), (R)(v1) }
+        // (COT: the first row holds the cotangents, the cosine row is unused)
         QMC_S128_ST(lS, up, ta[0].s, ta[1].s);
-        QMC_S128_ST(lC, up, ta[0].c, ta[1].c);
+        if (!COT) QMC_S128_ST(lC, up, ta[0].c, ta[1].c);
         QMC_S128_ST(lSU, up, ta[0].su, ta[1].su);
         QMC_S128_ST(lCU, up, ta[0].cu, ta[1].cu);
         QMC_S128_ST(lZ, up, z[0], z[1]);
         if (lo >= 2) {
-            // (COT: ta.s = cot, the same one period below; ta.c = position)
+            // (COT: ta.s = cot, the same one period below)
             if (COT) {
                 QMC_S128_ST(lS, lo, ta[0].s, ta[1].s);
-                QMC_S128_ST(lC, lo, z[0] - m.L, z[1] - m.L);
             } else {
                 QMC_S128_ST(lS, lo, -ta[0].s, -ta[1].s);
                 QMC_S128_ST(lC, lo, -ta[0].c, -ta[1].c);
@@ -182,9 +182,15 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                         fma(ta[1].cu, m.cth, ta[1].su * m.sth_signed));
             QMC_S128_ST(lZ, lo, z[0] - m.L, z[1] - m.L);
         }
-#undef QMC_S128_ST
+    } else if (REUSE && COT && live) {
+        // the energy pass after an accepted VMC move: sine row -> cotangent row
+        typedef typename SlotPair<R>::type R2;
+        const int up = H + 2 * gl, lo = up - n;
+        QMC_S128_ST(lS, up, ta[0].s, ta[1].s);
+        if (lo >= 2) QMC_S128_ST(lS, lo, ta[0].s, ta[1].s);
     }
-    if (!REUSE) {
+#undef QMC_S128_ST
+    if (!REUSE || COT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -196,7 +202,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                   __popcll(__ballot(ob[1].barrier & live));
     const R sin_rm = (R)m.sin_rm;
     // particle b of the partner lane of step k: entry (H + 2 gl) - 2 k + b
-    const R *pS = lS + H + 2 * gl, *pC = lC + H + 2 * gl,
+    const R *pS = lS + H + 2 * gl, *pC = (COT ? lZ : lC) + H + 2 * gl,
             *pSU = lSU + H + 2 * gl, *pCU = lCU + H + 2 * gl,
             *pZ = lZ + H + 2 * gl;
 

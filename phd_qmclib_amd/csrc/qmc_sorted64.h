@@ -63,13 +63,21 @@
 // never long.  Accuracy otherwise that of the two-table form (the quotient of
 // two correctly rounded operations on correctly rounded cotangents).
 // The log|psi| pass needs sin(pi D' / L) itself (the factor of the product),
-// so the VMC step keeps the sin / cos tables.
+// so that pass keeps the sin / cos tables.
 #ifndef QMC_COT
 #define QMC_COT 1
 #endif
+// The energy pass of the two-pass VMC step (REUSE: tables of this
+// configuration are in LDS) uses it too: every lane replaces its entries of the
+// sine row by the cotangent (one division per accepted move) and the loops take
+// the partner's position from the position row.
+#ifndef QMC_COT_REUSE
+#define QMC_COT_REUSE 1
+#endif
 template <bool WF, bool EN, bool REUSE>
 struct SortedCot {
-    static constexpr bool ON = QMC_COT && EN && !WF && !REUSE;
+    static constexpr bool ON = QMC_COT && EN && !WF &&
+                               (QMC_COT_REUSE || !REUSE);
 };
 
 // lane i takes the value of lane i - 1, lane 0 takes 0.0 (bound_ctrl: no
@@ -299,7 +307,7 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         // cotangent stays inside float)
         const double tiny = sizeof(R) == 4 ? 1e-25 : 1e-290;
         ta.s = fast_div(ta.c, fmax(ta.s, tiny));     // cot(pi z / L)
-        ta.c = z;                                     // second entry: position
+        ta.c = z;       // (o.c: the position -- the partner's comes from lZ)
     }
     o.s = (R)ta.s; o.c = (R)ta.c;
     const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
@@ -311,20 +319,28 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
     }
     o.zt = (R)(z - m.rm);
     if (WRITE && !REUSE && slot < n) {
-        lS[H + slot] = (R)ta.s; lC[H + slot] = (R)ta.c;
+        // (COT: the first row holds the cotangent, the cosine row is not used)
+        lS[H + slot] = (R)ta.s;
+        if (!COT) lC[H + slot] = (R)ta.c;
         lSU[H + slot] = (R)ta.su; lCU[H + slot] = (R)ta.cu;
         lZ[H + slot] = (R)z;
         // one period below: the entry the slots up to NS / 2 above the start
         // of the row find when they look past slot 0
         const int lo = H + slot - n;
         if (lo >= 1) {
-            // (cot: the same number one period below; its position is lZ's)
+            // (cot: the same number one period below)
             lS[lo] = COT ? (R)ta.s : (R)-ta.s;
-            lC[lo] = COT ? (R)(z - m.L) : (R)-ta.c;
+            if (!COT) lC[lo] = (R)-ta.c;
             lSU[lo] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
             lCU[lo] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
             lZ[lo] = (R)(z - m.L);
         }
+    } else if (WRITE && REUSE && COT && slot < n) {
+        // the energy pass after an accepted VMC move: sine row -> cotangent
+        // row (every lane rewrites its own entries only, and read them above)
+        lS[H + slot] = (R)ta.s;
+        const int lo = H + slot - n;
+        if (lo >= 1) lS[lo] = (R)ta.s;
     }
 }
 
@@ -371,7 +387,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         lA[H + gl] = 0.0;
         if (a_lo >= 1) lA[a_lo] = 0.0;
     }
-    if (!REUSE || T_LDS) {
+    if (!REUSE || T_LDS || COT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -383,8 +399,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     if (nb_counted) nb_wave = __popcll(__ballot(ob.barrier & live));
     const R sin_rm = (R)m.sin_rm;
     // partner of rotation step k: entry (H + gl) - k
-    const R *pS = lS + H + gl, *pC = lC + H + gl, *pSU = lSU + H + gl,
-            *pCU = lCU + H + gl, *pZ = lZ + H + gl;
+    // (COT: the second entry of a general step is the partner's position)
+    const R *pS = lS + H + gl, *pC = (COT ? lZ : lC) + H + gl,
+            *pSU = lSU + H + gl, *pCU = lCU + H + gl, *pZ = lZ + H + gl;
     typedef __attribute__((address_space(3))) double *lds_dptr;
     const lds_dptr pA = (lds_dptr)(lA + H + gl);
     // the lane below in the ring of the lanes in use (travelling sums)
