@@ -115,6 +115,7 @@ struct DevModel {
     double m_k2;           // -k2
     double m_k2_over_a;    // -k2 / a_long, a_long^2 (qmc_sorted64.h: Own64)
     double a_long_sq;
+    double m_a_over_k2;    // -a_long / k2 (the tangent form, qmc_sorted64.h)
     double sin_rm;         // sin(pi rm / L)
     double a_long, b_long; // (pi/L) beta, (pi/L)^2 beta
     double inv_beta;       // 1 / beta

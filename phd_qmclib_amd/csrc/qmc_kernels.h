@@ -54,14 +54,18 @@ __device__ __forceinline__ long long walker_of_block(unsigned b, int grp)
 // LDS doubles per lane group of the stepping kernels (vmc_step, dmc_evolve):
 // the sorted-row path of the exact N = 128 shape keeps the positions as well,
 // 5 rows of 192 entries (qmc_sorted64.h: sorted_particle_setup)
-template <int G, int P, bool PAD, bool ZC>
+// (DMC = the energy-only stepping kernel: three rows with the cotangent /
+// tangent tables, qmc_sorted64.h: SortedCot::COMPACT)
+template <int G, int P, bool PAD, bool ZC, bool DMC = false>
 struct StepLds {
+    static constexpr int NROWS =
+        DMC ? SortedCot<false, true, false>::ROWS : 5;
     // (+ one row of partner sums, qmc_sorted64.h: QMC_T_LDS)
     static constexpr int SORTED =
         (QMC_SORTED128 && G == 64 && P == 2 && !ZC)
-            ? 5 * SortedRows<128>::ROW
+            ? NROWS * SortedRows<128>::ROW
             : (QMC_SORTED64 && G == 64 && P == 1 && !ZC)
-                  ? (QMC_T_LDS ? 6 : 5) * SortedRows<64>::ROW
+                  ? (NROWS + (QMC_T_LDS ? 1 : 0)) * SortedRows<64>::ROW
                   : 0;
     // a walker that fails the per-walker checks of the sorted-row path runs
     // eval_walker on the same LDS region: room for the larger of the two
@@ -100,11 +104,14 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
 // (The VMC step of the exact N <= 128 shape held to 96 registers for a fifth
 // wave was 2.4 % faster with the four-case form; with the two-case form it needs
 // 108 registers unconstrained (4 waves) and the constraint costs 2.5 %: off.)
+// (Round 4: the production instantiation needs 94 on its own -- five waves --
+// but the series / tape instantiation was allotted 129, three waves: held to
+// four.)
 #ifndef QMC_LB_VMC_P2
-#define QMC_LB_VMC_P2 1
+#define QMC_LB_VMC_P2 4
 #endif
 #define QMC_LB_WAVES_VMC , ((G == 64 && P == 1) ? QMC_LB_P1 \
-                            : (G == 64 && P == 2 && !PAD) ? QMC_LB_VMC_P2 : 1)
+                            : (G == 64 && P == 2 && !ZC) ? QMC_LB_VMC_P2 : 1)
 
 // The VMC step in two passes (one wavefront per walker: the accept decision
 // is wave-uniform): log|psi| of the proposal first -- no quotient, no drift --
@@ -558,9 +565,10 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
     extern __shared__ double smem[];
     constexpr int GPB = WalkBlock<G>::N / G;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    static_assert(StepLds<G, P, PAD, ZC>::DOUBLES >= GroupLds<G, P, ZC>::DOUBLES,
+    static_assert(StepLds<G, P, PAD, ZC, true>::DOUBLES >=
+                      GroupLds<G, P, ZC>::DOUBLES,
                   "eval_walker is the fallback on the same LDS region");
-    double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC>::DOUBLES;
+    double *lds = smem + (size_t)grp * StepLds<G, P, PAD, ZC, true>::DOUBLES;
     const long long s = walker_of_block<GPB>(blockIdx.x, grp);
     const long long nw = a.ctl->nw;
     // whole block beyond the population: nothing to do

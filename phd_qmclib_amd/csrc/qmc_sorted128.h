@@ -134,8 +134,10 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     constexpr int G = 64, NS = 128, H = SortedRows<NS>::H,
                   ROW = SortedRows<NS>::ROW;
     constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;   // (qmc_sorted64.h)
-    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
-      *lZ = lS + 4 * ROW;
+    constexpr bool TAN = SortedCot<WF, EN, REUSE>::TAN;
+    typedef SortedCot<WF, EN, REUSE> RowsOf;
+    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + RowsOf::ROW_SU * ROW,
+      *lCU = lS + 3 * ROW, *lZ = lS + RowsOf::ROW_Z * ROW;
     const int n = PAD ? m.n : NS;            // particles (even)
     const int nl = n / 2;                    // lanes in use
     const int K = nl / 2;                    // rotation steps
@@ -149,45 +151,46 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     Own64<R> o[2];
     SortedOneBody ob[2];
     PTab ta[2];
+    SortedPub pub[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
         sorted_particle_setup<R, WF, EN, REUSE, NS, false>(
-            m, z[a], 2 * gl + a, (R *)lds, o[a], ob[a], n, ta[a]);
-    if (!REUSE && live) {
-        // both entries of the lane with one 16-byte store per row; the pair one
-        // period below for the lanes the rotation reaches around the row's end
-        typedef typename SlotPair<R>::type R2;
-        const int up = H + 2 * gl, lo = up - n;
+            m, z[a], 2 * gl + a, (R *)lds, o[a], ob[a], n, ta[a], pub[a]);
+    // both entries of the lane with one 16-byte store per row; the pair one
+    // period below for the lanes the rotation reaches around the row's end
+    // (COT: first row = cotangents, same one period below, no cosine row;
+    // TAN: k2 sine row = kappa tan(k2 z), no k2 cosine row)
 #define QMC_S128_ST(row, i, v0, v1)                                           \
-        *(R2 *)((row) + (i)) = R2{ (R)(v0), (R)(v1) }
-        // (COT: the first row holds the cotangents, the cosine row is unused)
-        QMC_S128_ST(lS, up, ta[0].s, ta[1].s);
-        if (!COT) QMC_S128_ST(lC, up, ta[0].c, ta[1].c);
-        QMC_S128_ST(lSU, up, ta[0].su, ta[1].su);
-        QMC_S128_ST(lCU, up, ta[0].cu, ta[1].cu);
+        *(typename SlotPair<R>::type *)((row) + (i)) =                        \
+            typename SlotPair<R>::type{ (R)(v0), (R)(v1) }
+    if (!REUSE && live) {
+        const int up = H + 2 * gl, lo = up - n;
+        QMC_S128_ST(lS, up, pub[0].s, pub[1].s);
+        if (!COT) QMC_S128_ST(lC, up, pub[0].c, pub[1].c);
+        QMC_S128_ST(lSU, up, pub[0].su, pub[1].su);
+        if (!TAN) QMC_S128_ST(lCU, up, pub[0].cu, pub[1].cu);
         QMC_S128_ST(lZ, up, z[0], z[1]);
         if (lo >= 2) {
-            // (COT: ta.s = cot, the same one period below)
             if (COT) {
-                QMC_S128_ST(lS, lo, ta[0].s, ta[1].s);
+                QMC_S128_ST(lS, lo, pub[0].s, pub[1].s);
             } else {
-                QMC_S128_ST(lS, lo, -ta[0].s, -ta[1].s);
-                QMC_S128_ST(lC, lo, -ta[0].c, -ta[1].c);
+                QMC_S128_ST(lS, lo, -pub[0].s, -pub[1].s);
+                QMC_S128_ST(lC, lo, -pub[0].c, -pub[1].c);
             }
-            QMC_S128_ST(lSU, lo,
-                        fma(ta[0].su, m.cth, -(ta[0].cu * m.sth_signed)),
-                        fma(ta[1].su, m.cth, -(ta[1].cu * m.sth_signed)));
-            QMC_S128_ST(lCU, lo,
-                        fma(ta[0].cu, m.cth, ta[0].su * m.sth_signed),
-                        fma(ta[1].cu, m.cth, ta[1].su * m.sth_signed));
+            QMC_S128_ST(lSU, lo, pub[0].su_lo, pub[1].su_lo);
+            if (!TAN) QMC_S128_ST(lCU, lo, pub[0].cu_lo, pub[1].cu_lo);
             QMC_S128_ST(lZ, lo, z[0] - m.L, z[1] - m.L);
         }
     } else if (REUSE && COT && live) {
-        // the energy pass after an accepted VMC move: sine row -> cotangent row
-        typedef typename SlotPair<R>::type R2;
+        // the energy pass after an accepted VMC move: sine row -> cotangent
+        // row, k2 sine row -> tangent row
         const int up = H + 2 * gl, lo = up - n;
-        QMC_S128_ST(lS, up, ta[0].s, ta[1].s);
-        if (lo >= 2) QMC_S128_ST(lS, lo, ta[0].s, ta[1].s);
+        QMC_S128_ST(lS, up, pub[0].s, pub[1].s);
+        if (TAN) QMC_S128_ST(lSU, up, pub[0].su, pub[1].su);
+        if (lo >= 2) {
+            QMC_S128_ST(lS, lo, pub[0].s, pub[1].s);
+            if (TAN) QMC_S128_ST(lSU, lo, pub[0].su_lo, pub[1].su_lo);
+        }
     }
 #undef QMC_S128_ST
     if (!REUSE || COT) {
@@ -227,10 +230,13 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
 
     // a short-range pair of own particle `oa` with the partner's k2-table
     // (bsu, bcu): numerator / denominator of the one-case form
+    // (TAN, qmc_sorted64.h: bsu = the partner's kappa tan(k2 z'), bcu unused)
 #define QMC_S128_SHORT_XY(oa, bsu, bcu, X, Y)                                 \
-    const R Y = (oa).c0 * (bcu) + (oa).s0 * (bsu);                            \
+    const R Y = TAN ? q_fma((oa).c0, (bsu), (R)1)                             \
+                    : (oa).c0 * (bcu) + (oa).s0 * (bsu);                      \
     R X = 0;                                                                  \
-    if (EN) X = (oa).ks0 * (bcu) - (oa).kc0 * (bsu);
+    if (EN) X = TAN ? (oa).s0 - (bsu)                                         \
+                    : (oa).ks0 * (bcu) - (oa).kc0 * (bsu);
     // a pair of a general step: class from the sine, short ones recomputed in
     // an exec-masked region
     // (bsu, bcu: the partner's k2-table entry.  QMC_S128_SU_PAIRS: read for
@@ -251,9 +257,15 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \
         asm volatile("");                                                     \
-        const R bsu_ = (bsu), bcu_ = (bcu);                                   \
-        Y = (oa).c0 * bcu_ + (oa).s0 * bsu_;                                  \
-        if (EN) X = (oa).ks0 * bcu_ - (oa).kc0 * bsu_;                        \
+        const R bsu_ = (bsu);                                                 \
+        if (TAN) {                                                            \
+            Y = q_fma((oa).c0, bsu_, (R)1);                                   \
+            X = (oa).s0 - bsu_;                                               \
+        } else {                                                              \
+            const R bcu_ = (bcu);                                             \
+            Y = (oa).c0 * bcu_ + (oa).s0 * bsu_;                              \
+            if (EN) X = (oa).ks0 * bcu_ - (oa).kc0 * bsu_;                    \
+        }                                                                     \
     }
 
     // ---- k = 0: the pair inside the lane (slot 1 against slot 0) ----
@@ -301,9 +313,10 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
     {
         // set A: step k, set B: step k + 1 (entries of both partner particles)
         typedef typename SlotPair<R>::type R2;
-        R2 asu = ld_pair(pSU - 2), acu = ld_pair(pCU - 2);
+        // (TAN: the cosine row of the k2-table is neither written nor read)
+        R2 asu = ld_pair(pSU - 2), acu = TAN ? asu : ld_pair(pCU - 2);
         R az = pZ[-2];
-        R2 bsu = ld_pair(pSU - 4), bcu = ld_pair(pCU - 4);
+        R2 bsu = ld_pair(pSU - 4), bcu = TAN ? bsu : ld_pair(pCU - 4);
         R bz = pZ[-4];
         // (the farthest pair of a step: own slot 1 against the partner's slot 0)
         const R zt = o[1].zt;
@@ -311,12 +324,14 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         while (k < kfull) {
             if (!QMC_S128_ALL(az > zt)) break;
             QMC_S128_LEAD(asu[0], acu[0], asu[1], acu[1])
-            asu = ld_pair(pSU - 2 * (k + 2)); acu = ld_pair(pCU - 2 * (k + 2));
+            asu = ld_pair(pSU - 2 * (k + 2));
+            if (!TAN) acu = ld_pair(pCU - 2 * (k + 2));
             az = pZ[-2 * (k + 2)];
             ++k;
             if (!QMC_S128_ALL(bz > zt)) break;
             QMC_S128_LEAD(bsu[0], bcu[0], bsu[1], bcu[1])
-            bsu = ld_pair(pSU - 2 * (k + 2)); bcu = ld_pair(pCU - 2 * (k + 2));
+            bsu = ld_pair(pSU - 2 * (k + 2));
+            if (!TAN) bcu = ld_pair(pCU - 2 * (k + 2));
             bz = pZ[-2 * (k + 2)];
             ++k;
             if (WF) {
@@ -338,7 +353,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
 #if QMC_S128_SU_PAIRS
 #define QMC_S128_SU_LOAD(kk)                                                  \
         const typename SlotPair<R>::type su_ = ld_pair(pSU - 2 * (kk)),       \
-                                         cu_ = ld_pair(pCU - 2 * (kk));
+            cu_ = TAN ? su_ : ld_pair(pCU - 2 * (kk));
 #define QMC_S128_SU(kk, b) su_[b]
 #define QMC_S128_CU(kk, b) cu_[b]
 #else

@@ -74,11 +74,46 @@
 #ifndef QMC_COT_REUSE
 #define QMC_COT_REUSE 1
 #endif
+// The short-range pairs of the same passes, likewise from one number per
+// particle: with A = k2 z_i - phi (own) and B = k2 z'_j (partner),
+//   f2'/f2 = -k2 tan(A - B) = -k2 (tan A - tan B) / (1 + tan A tan B):
+// the own table holds u = kappa tan A and w = tan A / kappa, the partner's row
+// v = kappa tan B (kappa = -k2 / a_long, the unit of the quotients), and
+//   X = u_i - v_j,  Y = 1 + w_i v_j
+// are one fp64 instruction each instead of two, from ONE partner entry instead
+// of two (the cosine row of the k2-table is not used either).  tan has poles
+// inside the box; the identity does not care -- a huge tan A against an
+// ordinary tan B gives -kappa / tan B with the relative error of the operands --
+// and two huge ones cannot meet in a short pair: its angle A - B lies in
+// (-phi, k2 rm - phi), inside (-pi/2, 0) and bounded away from 0 by the model
+// (the trial function rises all the way to rm).  The denominators of the
+// per-particle tangents are clamped away from zero (sign kept) so that no
+// product overflows.  Accuracy: the reference's golden configurations through
+// this form, tests/test_gpu_sorted_pins.py, 2e-11.
+#ifndef QMC_TAN
+#define QMC_TAN 1
+#endif
 template <bool WF, bool EN, bool REUSE>
 struct SortedCot {
     static constexpr bool ON = QMC_COT && EN && !WF &&
                                (QMC_COT_REUSE || !REUSE);
+    static constexpr bool TAN = ON && QMC_TAN;
+    // The DMC step (energy only, tables built here) then uses THREE rows --
+    // cotangent, kappa tan(k2 z), position -- and keeps them together: 4.7 KB
+    // per walker at N = 128 instead of 7.8 (the VMC step needs all five rows
+    // for its log|psi| pass and keeps the five-row layout in both passes).
+    static constexpr bool COMPACT = TAN && !REUSE;
+    static constexpr int ROW_SU = COMPACT ? 1 : 2;
+    static constexpr int ROW_Z = COMPACT ? 2 : 4;
+    static constexpr int ROWS = COMPACT ? 3 : 5;
 };
+
+// x / y with |y| kept above `tiny` (sign of y kept; y = 0 counts as positive)
+__device__ __forceinline__ double div_clamped(double x, double y, double tiny)
+{
+    const double ya = fmax(__builtin_fabs(y), tiny);
+    return fast_div(x, __builtin_copysign(ya, y));
+}
 
 // lane i takes the value of lane i - 1, lane 0 takes 0.0 (bound_ctrl: no
 // copy of the old value first -- one v_mov_b32_dpp per word instead of two
@@ -260,18 +295,26 @@ struct SortedRows {
                   "two slots per lane: 16-byte aligned pairs");
 };
 
-// WRITE = false: the caller publishes the entries itself from `ta` (two slots
+// What a particle publishes in the LDS rows: its entries of the first / second
+// row and of the k2 rows, and the k2 entries of its image one period below.
+struct SortedPub {
+    double s, c, su, cu, su_lo, cu_lo;
+};
+
+// WRITE = false: the caller publishes the entries itself from `pub` (two slots
 // per lane: both particles of a lane with one 16-byte store per row).
 template <typename R, bool WF, bool EN, bool REUSE, int NS, bool WRITE = true>
 __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double z,
                                                       int slot, R *tab,
                                                       Own64<R> &o,
                                                       SortedOneBody &ob,
-                                                      int n, PTab &ta)
+                                                      int n, PTab &ta,
+                                                      SortedPub &pub)
 {
     constexpr int H = SortedRows<NS>::H, ROW = SortedRows<NS>::ROW;
-    R *lS = tab, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
-      *lZ = lS + 4 * ROW;
+    typedef SortedCot<WF, EN, REUSE> RowsOf;
+    R *lS = tab, *lC = lS + ROW, *lSU = lS + RowsOf::ROW_SU * ROW,
+      *lCU = lS + 3 * ROW, *lZ = lS + RowsOf::ROW_Z * ROW;
     TrigRow trow;
     const bool trig_ok = !REUSE && m.trig_table && trig_tab_load(m, z, trow);
     if (!m.is_free && m.ob_table) {
@@ -302,45 +345,67 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
         sincos_halfpi(z * m.k2_2pi, ta.su, ta.cu);
     }
     constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
+    constexpr bool TAN = SortedCot<WF, EN, REUSE>::TAN;
+    // (clamps: products of two clamped quantities stay finite, in float too)
+    const double tiny = sizeof(R) == 4 ? 1e-18 : 1e-140;
+    // what the partners read of this particle (first row, second row, k2 rows)
+    pub.s = ta.s; pub.c = ta.c; pub.su = ta.su; pub.cu = ta.cu;
     if (COT) {
-        // (s >= 0 inside the box; float pair loop: 1e25 times a long partner's
-        // cotangent stays inside float)
-        const double tiny = sizeof(R) == 4 ? 1e-25 : 1e-290;
-        ta.s = fast_div(ta.c, fmax(ta.s, tiny));     // cot(pi z / L)
-        ta.c = z;       // (o.c: the position -- the partner's comes from lZ)
+        // (s >= 0 inside the box)
+        pub.s = fast_div(ta.c, fmax(ta.s, tiny));    // cot(pi z / L)
+        pub.c = z;      // (o.c: the position -- the partner's comes from lZ)
     }
-    o.s = (R)ta.s; o.c = (R)ta.c;
+    o.s = (R)pub.s; o.c = (R)pub.c;
     const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
     const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
-    o.s0 = (R)s0; o.c0 = (R)c0;
-    if (EN) {
-        o.ks0 = (R)(m.m_k2_over_a * s0);
-        o.kc0 = (R)(m.m_k2_over_a * c0);
+    // the k2 entry one period below: rotation by k2 L
+    pub.su_lo = fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
+    pub.cu_lo = fma(ta.cu, m.cth, ta.su * m.sth_signed);
+    if (TAN) {
+        const double tA = div_clamped(s0, c0, tiny);          // tan(k2 z - phi)
+        o.s0 = (R)(m.m_k2_over_a * tA);                       // u
+        o.c0 = (R)(tA * m.m_a_over_k2);                       // w = tan A / kappa
+        // kappa tan(k2 z), and of the image one period below
+        pub.su = m.m_k2_over_a * div_clamped(ta.su, ta.cu, tiny);
+        pub.su_lo = m.m_k2_over_a * div_clamped(pub.su_lo, pub.cu_lo, tiny);
+    } else {
+        o.s0 = (R)s0; o.c0 = (R)c0;
+        if (EN) {
+            o.ks0 = (R)(m.m_k2_over_a * s0);
+            o.kc0 = (R)(m.m_k2_over_a * c0);
+        }
     }
     o.zt = (R)(z - m.rm);
     if (WRITE && !REUSE && slot < n) {
-        // (COT: the first row holds the cotangent, the cosine row is not used)
-        lS[H + slot] = (R)ta.s;
-        if (!COT) lC[H + slot] = (R)ta.c;
-        lSU[H + slot] = (R)ta.su; lCU[H + slot] = (R)ta.cu;
+        // (COT: the first row holds the cotangent, the cosine row is not used;
+        // TAN: the k2 sine row holds kappa tan(k2 z), its cosine row is not used)
+        lS[H + slot] = (R)pub.s;
+        if (!COT) lC[H + slot] = (R)pub.c;
+        lSU[H + slot] = (R)pub.su;
+        if (!TAN) lCU[H + slot] = (R)pub.cu;
         lZ[H + slot] = (R)z;
         // one period below: the entry the slots up to NS / 2 above the start
         // of the row find when they look past slot 0
         const int lo = H + slot - n;
         if (lo >= 1) {
             // (cot: the same number one period below)
-            lS[lo] = COT ? (R)ta.s : (R)-ta.s;
-            if (!COT) lC[lo] = (R)-ta.c;
-            lSU[lo] = (R)fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
-            lCU[lo] = (R)fma(ta.cu, m.cth, ta.su * m.sth_signed);
+            lS[lo] = COT ? (R)pub.s : (R)-pub.s;
+            if (!COT) lC[lo] = (R)-pub.c;
+            lSU[lo] = (R)pub.su_lo;
+            if (!TAN) lCU[lo] = (R)pub.cu_lo;
             lZ[lo] = (R)(z - m.L);
         }
     } else if (WRITE && REUSE && COT && slot < n) {
         // the energy pass after an accepted VMC move: sine row -> cotangent
-        // row (every lane rewrites its own entries only, and read them above)
-        lS[H + slot] = (R)ta.s;
+        // row, k2 sine row -> tangent row (every lane rewrites its own entries
+        // only, and has read them above)
+        lS[H + slot] = (R)pub.s;
+        if (TAN) lSU[H + slot] = (R)pub.su;
         const int lo = H + slot - n;
-        if (lo >= 1) lS[lo] = (R)ta.s;
+        if (lo >= 1) {
+            lS[lo] = (R)pub.s;
+            if (TAN) lSU[lo] = (R)pub.su_lo;
+        }
     }
 }
 
@@ -360,11 +425,13 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
 {
     constexpr int G = 64, H = SortedRows<G>::H, ROW = SortedRows<G>::ROW;
     constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
-    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + 2 * ROW, *lCU = lS + 3 * ROW,
-      *lZ = lS + 4 * ROW;
+    constexpr bool TAN = SortedCot<WF, EN, REUSE>::TAN;
+    typedef SortedCot<WF, EN, REUSE> RowsOf;
+    R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + RowsOf::ROW_SU * ROW,
+      *lCU = lS + 3 * ROW, *lZ = lS + RowsOf::ROW_Z * ROW;
     // sixth row (double whatever R is): the sums the partners collect
     constexpr bool T_LDS = QMC_T_LDS && EN;
-    double *lA = lds + 5 * ROW;
+    double *lA = lds + RowsOf::ROWS * ROW;
     const int nl = PAD ? m.n : G;            // lanes in use = particles
     const int K = nl / 2;                    // rotation steps
     const bool half_last = !PAD || (nl & 1) == 0;   // step K is a half step
@@ -377,8 +444,9 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     Own64<R> o;
     SortedOneBody ob;
     PTab ta_own;
+    SortedPub pub_own;
     sorted_particle_setup<R, WF, EN, REUSE, G>(m, z, gl, (R *)lds, o, ob, nl,
-                                               ta_own);
+                                               ta_own, pub_own);
     // (where the shares of this lane's particle arrive: its own index from the
     // lanes above it, the index one period below from the lanes that reach it
     // around the end of the row)
@@ -429,10 +497,13 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     // step; unrolled by its constant trip count the kernel is 25 KB.)
     QMC_SECTION("leading_short_steps");
     // numerator / denominator of a leading (all-short) step
+    // (TAN: bsu = the partner's kappa tan(k2 z'), bcu is not read)
 #define QMC_S64_LEAD_XY(bsu, bcu, X, Y)                                       \
-    const R Y = o.c0 * (bcu) + o.s0 * (bsu);  /* f2 = |a_m| cos(k2 D' - phi) */ \
+    const R Y = TAN ? q_fma(o.c0, (bsu), (R)1)      /* 1 + w_i v_j */          \
+                    : o.c0 * (bcu) + o.s0 * (bsu);  /* f2 = |a_m| cos(k2 D' - phi) */ \
     R X = 0;                                                                  \
-    if (EN) X = o.ks0 * (bcu) - o.kc0 * (bsu);                                \
+    if (EN) X = TAN ? o.s0 - (bsu)                  /* u_i - v_j */            \
+                    : o.ks0 * (bcu) - o.kc0 * (bsu);                          \
     if (WF) PS *= Y;
     // the quotient's way into the sums of step kk (not the last step)
 #define QMC_S64_ADD_Q(q, kk)                                                  \
@@ -451,14 +522,18 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
 #define QMC_S64_ALL(cond)                                                     \
     ((__builtin_amdgcn_ballot_w64(cond) | ~live_mask) == ~0ull)
     {
-        R asu = lds_ahead(pSU - 1), acu = lds_ahead(pCU - 1), az = lds_ahead(pZ - 1);
-        R bsu = lds_ahead(pSU - 2), bcu = lds_ahead(pCU - 2), bz = lds_ahead(pZ - 2);
+        // (TAN: the cosine row of the k2-table is not read -- nor written)
+        R asu = lds_ahead(pSU - 1), acu = TAN ? (R)0 : lds_ahead(pCU - 1),
+          az = lds_ahead(pZ - 1);
+        R bsu = lds_ahead(pSU - 2), bcu = TAN ? (R)0 : lds_ahead(pCU - 2),
+          bz = lds_ahead(pZ - 2);
         // (k odd at the top; both steps of a trip are full steps)
 #pragma clang loop unroll(disable)
         while (k < kfull) {
             if (!QMC_S64_ALL(az > o.zt)) break;
             QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
-            asu = lds_ahead(pSU - (k + 2)); acu = lds_ahead(pCU - (k + 2));
+            asu = lds_ahead(pSU - (k + 2));
+            if (!TAN) acu = lds_ahead(pCU - (k + 2));
             az = lds_ahead(pZ - (k + 2));
             ++k;
             if (!QMC_S64_ALL(bz > o.zt)) {
@@ -470,7 +545,8 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                 break;
             }
             QMC_S64_LEAD_XY(bsu, bcu, Xb, Yb)
-            bsu = lds_ahead(pSU - (k + 2)); bcu = lds_ahead(pCU - (k + 2));
+            bsu = lds_ahead(pSU - (k + 2));
+            if (!TAN) bcu = lds_ahead(pCU - (k + 2));
             bz = lds_ahead(pZ - (k + 2));
             ++k;
             if (EN) {
@@ -508,9 +584,15 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \
         asm volatile("");                      /* exec-masked, not selects */  \
-        const R bsu_ = pSU[-(kk)], bcu_ = pCU[-(kk)];                         \
-        Y = o.c0 * bcu_ + o.s0 * bsu_;                                        \
-        if (EN) X = o.ks0 * bcu_ - o.kc0 * bsu_;                              \
+        const R bsu_ = pSU[-(kk)];                                            \
+        if (TAN) {                                                            \
+            Y = q_fma(o.c0, bsu_, (R)1);                                      \
+            X = o.s0 - bsu_;                                                  \
+        } else {                                                              \
+            const R bcu_ = pCU[-(kk)];                                        \
+            Y = o.c0 * bcu_ + o.s0 * bsu_;                                    \
+            if (EN) X = o.ks0 * bcu_ - o.kc0 * bsu_;                          \
+        }                                                                     \
         if (WF && mine) PS *= Y;                                              \
     }                                                                         \
     if (WF && mine) PL *= Y;

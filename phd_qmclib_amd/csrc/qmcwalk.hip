@@ -158,11 +158,11 @@ static size_t lds_bytes()
 }
 
 // (the stepping kernels: StepLds, qmc_kernels.h)
-template <int G, int P, bool PAD, bool ZC>
+template <int G, int P, bool PAD, bool ZC, bool DMC = false>
 static size_t step_lds_bytes()
 {
-    return (size_t)(WalkBlock<G>::N / G) * StepLds<G, P, PAD, ZC>::DOUBLES *
-           sizeof(double);
+    return (size_t)(WalkBlock<G>::N / G) *
+           StepLds<G, P, PAD, ZC, DMC>::DOUBLES * sizeof(double);
 }
 
 // Dynamic LDS above the default limit must be opted into per kernel.
@@ -294,7 +294,7 @@ struct LaunchEvolve {
     static constexpr bool want_mask(int np) { return np >= 4; }
     static int run(const qmc_engine *e, const EvolveArgs &a)
     {
-        const size_t lds = step_lds_bytes<G, P, PAD, ZC>();
+        const size_t lds = step_lds_bytes<G, P, PAD, ZC, true>();
         ProfScope prof(e);
         if constexpr (has_fast<G, ZC>()) {
             if (e->fast) {
@@ -371,6 +371,7 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.b_long = pi_L * pi_L * p.param_beta;
     d.a_long_sq = d.a_long * d.a_long;
     d.m_k2_over_a = d.a_long != 0.0 ? -d.k2 / d.a_long : 0.0;
+    d.m_a_over_k2 = d.k2 != 0.0 ? -d.a_long / d.k2 : 0.0;
     d.beta = p.param_beta;
     d.inv_beta = p.param_beta != 0.0 ? 1.0 / p.param_beta : 0.0;
     d.log_am = log(fabs(p.param_am));
