@@ -346,35 +346,63 @@ __device__ __forceinline__ void sorted_particle_setup(const DevModel &m, double 
     }
     constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
     constexpr bool TAN = SortedCot<WF, EN, REUSE>::TAN;
-    // (clamps: products of two clamped quantities stay finite, in float too)
-    const double tiny = sizeof(R) == 4 ? 1e-18 : 1e-140;
     // what the partners read of this particle (first row, second row, k2 rows)
     pub.s = ta.s; pub.c = ta.c; pub.su = ta.su; pub.cu = ta.cu;
-    if (COT) {
-        // (s >= 0 inside the box)
-        pub.s = fast_div(ta.c, fmax(ta.s, tiny));    // cot(pi z / L)
-        pub.c = z;      // (o.c: the position -- the partner's comes from lZ)
-    }
-    o.s = (R)pub.s; o.c = (R)pub.c;
     const double s0 = fma(ta.su, m.am_cphi, -(ta.cu * m.am_sphi));
     const double c0 = fma(ta.cu, m.am_cphi, ta.su * m.am_sphi);
     // the k2 entry one period below: rotation by k2 L
     pub.su_lo = fma(ta.su, m.cth, -(ta.cu * m.sth_signed));
     pub.cu_lo = fma(ta.cu, m.cth, ta.su * m.sth_signed);
-    if (TAN) {
-        const double tA = div_clamped(s0, c0, tiny);          // tan(k2 z - phi)
-        o.s0 = (R)(m.m_k2_over_a * tA);                       // u
-        o.c0 = (R)(tA * m.m_a_over_k2);                       // w = tan A / kappa
-        // kappa tan(k2 z), and of the image one period below
-        pub.su = m.m_k2_over_a * div_clamped(ta.su, ta.cu, tiny);
-        pub.su_lo = m.m_k2_over_a * div_clamped(pub.su_lo, pub.cu_lo, tiny);
+    if (COT && TAN) {
+        // cot(pi z / L) = c / s, tan(k2 z - phi) = s0 / c0, tan(k2 z) = su / cu
+        // and tan(k2 z - k2 L) = su_lo / cu_lo: FOUR quotients from ONE
+        // reciprocal (of the product of the denominators; 15 fp64 operations
+        // and one v_rcp_f64 instead of 20 and four).  Denominators are kept
+        // away from zero (sign kept; 1e-70: the product of four of them and of
+        // two of the quotients stays finite); the float pair loop clamps the
+        // quotients into float's range as well.
+        const double tiny = 1e-70;
+        const double d0 = fmax(ta.s, tiny);            // (s >= 0 inside the box)
+        const double d1 = __builtin_copysign(fmax(__builtin_fabs(c0), tiny), c0);
+        const double d2 = __builtin_copysign(fmax(__builtin_fabs(ta.cu), tiny),
+                                             ta.cu);
+        const double d3 = __builtin_copysign(
+            fmax(__builtin_fabs(pub.cu_lo), tiny), pub.cu_lo);
+        const double p01 = d0 * d1, p23 = d2 * d3, pall = p01 * p23;
+        double r = __builtin_amdgcn_rcp(pall);
+        r = fma(fma(-pall, r, 1.0), r, r);
+        r = fma(fma(-pall, r, 1.0), r, r);
+        const double i01 = p23 * r, i23 = p01 * r;      // 1 / p01, 1 / p23
+        double cotz = ta.c * (i01 * d1);
+        double tA = s0 * (i01 * d0);
+        double tB = ta.su * (i23 * d3);
+        double tBl = pub.su_lo * (i23 * d2);
+        if (sizeof(R) == 4) {
+            const double big = 1e18;
+            cotz = fmin(fmax(cotz, -big), big); tA = fmin(fmax(tA, -big), big);
+            tB = fmin(fmax(tB, -big), big); tBl = fmin(fmax(tBl, -big), big);
+        }
+        pub.s = cotz;
+        pub.c = z;      // (o.c: the position -- the partner's comes from lZ)
+        o.s0 = (R)(m.m_k2_over_a * tA);                  // u = kappa tan A
+        o.c0 = (R)(tA * m.m_a_over_k2);                  // w = tan A / kappa
+        pub.su = m.m_k2_over_a * tB;                     // kappa tan(k2 z)
+        pub.su_lo = m.m_k2_over_a * tBl;
     } else {
+        // (clamp: the product of two clamped quantities stays finite)
+        const double tiny = sizeof(R) == 4 ? 1e-18 : 1e-140;
+        if (COT) {
+            // (s >= 0 inside the box)
+            pub.s = fast_div(ta.c, fmax(ta.s, tiny));    // cot(pi z / L)
+            pub.c = z;
+        }
         o.s0 = (R)s0; o.c0 = (R)c0;
         if (EN) {
             o.ks0 = (R)(m.m_k2_over_a * s0);
             o.kc0 = (R)(m.m_k2_over_a * c0);
         }
     }
+    o.s = (R)pub.s; o.c = (R)pub.c;
     o.zt = (R)(z - m.rm);
     if (WRITE && !REUSE && slot < n) {
         // (COT: the first row holds the cotangent, the cosine row is not used;
