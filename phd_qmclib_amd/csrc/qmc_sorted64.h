@@ -93,6 +93,15 @@
 #ifndef QMC_TAN
 #define QMC_TAN 1
 #endif
+// The log|psi| pass with the pair class from the positions (QMC_WF_ZCLASS): a
+// long lane computes the sine and multiplies it into the product of the long
+// factors, a short lane computes the short-range factor and multiplies it into
+// the product of the short ones -- the same instructions as with the class
+// from the sine (which every lane computed first), but each on the lanes that
+// need it only: fewer fp64 operations on live lanes, one more LDS read per step.
+#ifndef QMC_WF_ZCLASS
+#define QMC_WF_ZCLASS 0
+#endif
 template <bool WF, bool EN, bool REUSE>
 struct SortedCot {
     static constexpr bool ON = QMC_COT && EN && !WF &&
@@ -454,6 +463,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     constexpr int G = 64, H = SortedRows<G>::H, ROW = SortedRows<G>::ROW;
     constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
     constexpr bool TAN = SortedCot<WF, EN, REUSE>::TAN;
+    constexpr bool ZW = QMC_WF_ZCLASS && WF && !EN;   // (PL = long factors only)
     typedef SortedCot<WF, EN, REUSE> RowsOf;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + RowsOf::ROW_SU * ROW,
       *lCU = lS + 3 * ROW, *lZ = lS + RowsOf::ROW_Z * ROW;
@@ -592,13 +602,30 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     }
 #undef QMC_S64_LEAD_XY
     // (these pairs belong to both products and both sums)
-    if (WF) { PL = PS; eL = eS; }
+    if (WF && !ZW) { PL = PS; eL = eS; }
     if (EN) { Qall = Qs; ns = (k - 1) * nl; }
 
     // ---- general steps: classified pair by pair ----
     QMC_SECTION("rotation_loop_body");
     // numerator / denominator / class of a general step
     // (COT: cs = the partner's cotangent, cc = its position)
+    // (ZW: the log|psi| pass with the class from the partner's position zj)
+#define QMC_S64_ZW(cs, cc, zj, kk, LAST)                                      \
+    {                                                                         \
+        const bool mine = live & (!(LAST) || gl < K);                         \
+        const bool sh = (zj) > o.zt;                                          \
+        if (!sh) {                                                            \
+            asm volatile("");                                                 \
+            const R Y = o.s * (cc) - o.c * (cs);                              \
+            if (mine) PL *= Y;                                                \
+        }                                                                     \
+        if (sh) {                                                             \
+            asm volatile("");                                                 \
+            const R bsu_ = pSU[-(kk)], bcu_ = pCU[-(kk)];                     \
+            const R Y = o.c0 * bcu_ + o.s0 * bsu_;                            \
+            if (mine) PS *= Y;                                                \
+        }                                                                     \
+    }
 #define QMC_S64_XY(cs, cc, kk, LAST, X, Y, sh, mine)                          \
     const R Y##_s = COT ? (cs) - o.s           /* t_j - t_i */                 \
                         : o.s * (cc) - o.c * (cs);  /* sin(pi D' / L) >= 0 */  \
@@ -633,7 +660,32 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
             Qs = q_fma(q, q, Qs);                                             \
         }                                                                     \
     }
-    {
+    if constexpr (ZW) {
+        R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k), az_ = lds_ahead(pZ - k);
+        R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1)),
+          bz_ = lds_ahead(pZ - (k + 1));
+#pragma clang loop unroll(disable)
+        while (k < kfull) {
+            QMC_S64_ZW(as_, ac_, az_, k, false)
+            as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
+            az_ = lds_ahead(pZ - (k + 2));
+            QMC_S64_ZW(bs_, bc_, bz_, k + 1, false)
+            bs_ = lds_ahead(pS - (k + 3)); bc_ = lds_ahead(pC - (k + 3));
+            bz_ = lds_ahead(pZ - (k + 3));
+            k += 2;
+            if (sizeof(R) == 4) {
+                q_fold(PS, eS);
+                q_fold(PL, eL);
+            }
+        }
+        if (k <= kfull) {
+            QMC_S64_ZW(as_, ac_, az_, k, false)
+            ++k;
+            as_ = bs_; ac_ = bc_; az_ = bz_;
+        }
+        QMC_SECTION("rotation_last_step");
+        if (half_last) QMC_S64_ZW(as_, ac_, az_, k, true)
+    } else {
         R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k);   // step k
         // step k + 1 (<= K + 1: inside the rows)
         R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1));
@@ -683,6 +735,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         }
     }
 #undef QMC_S64_XY
+#undef QMC_S64_ZW
 #undef QMC_S64_TALLY
 #undef QMC_S64_ADD_Q
 #undef QMC_S64_ALL
@@ -723,7 +776,11 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     if (WF) {
         const double LN2 = 0.693147180559945309417;
         const double PS_d = (double)PS, PL_d = (double)PL;
-        if (!m.is_free && m.ob_table) {
+        if (ZW) {
+            // (PL: the long factors alone)
+            lw = fma(m.beta, log_pos(PL_d),
+                     log_pos((!m.is_free && m.ob_table) ? PS_d : prod1 * PS_d));
+        } else if (!m.is_free && m.ob_table) {
             const double lSv = log_pos(PS_d);
             lw = fma(m.beta, log_pos(PL_d) - lSv, lSv);
         } else {
@@ -731,7 +788,8 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                  m.beta * log_pos(fast_div(PL_d, PS_d));
         }
         if (sizeof(R) == 4)
-            lw += LN2 * ((double)eS + m.beta * (double)(eL - eS));
+            lw += LN2 * ((double)eS +
+                         m.beta * (double)(ZW ? eL : eL - eS));
         lw -= xoff;
         if (PAD && !live) lw = 0.0;
     }

@@ -184,15 +184,19 @@ def test_sorted_paths_random_specs_vs_oracle(oracle):
     + drift) against the oracle's evaluation, 2e-11, with random and with
     ordered configurations (particles on the poles of the tangents included:
     z = (pi/2 + phi) / k2, pi / (2 k2) when they lie inside the box)."""
+    import os
     from math import pi
     from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine, VmcEnsemble
     from phd_qmclib_amd.mrbp_qmc import Spec
     rng = np.random.RandomState(20261005)
     sizes = [33, 37, 48, 63, 64, 66, 100, 126, 128]
+    # (QMC_FUZZ_SPECS=400: the campaign recorded in profiles/r04_fuzz_sorted.txt)
+    count = int(os.environ.get('QMC_FUZZ_SPECS', 27))
     done = tried = 0
-    while done < 27:
+    worst = {}
+    while done < count:
         tried += 1
-        assert tried < 400
+        assert tried < 20 * count
         n = sizes[done % len(sizes)]
         L = float(np.round(n * rng.uniform(0.6, 1.6), 3))
         kw = dict(lattice_depth=float(rng.choice([0.0, rng.uniform(1, 120)])),
@@ -234,25 +238,26 @@ def test_sorted_paths_random_specs_vs_oracle(oracle):
         v = VmcEnsemble(eng, W, 0.1, rng_seed=3)
         v.set_state(pos)
         out = v.run_block(1, series=True)
-        assert np.all(np.abs(out['energy'][0] - en) <= 2e-11 * np.maximum(
-            scale_e, np.abs(en))), (kw, 'vmc energy')
-        assert np.all(np.abs(out['wf_abs_log'][0] - wf) <= 2e-11 * np.maximum(
-            1.0, np.abs(wf))), (kw, 'vmc wf')
+        def rel(name, got, ref, scale):
+            err = float((np.abs(got - ref) / scale).max())
+            worst[name] = max(worst.get(name, 0.0), err)
+            assert err <= 2e-11, (kw, name, err)
+        rel('vmc energy', out['energy'][0], en, np.maximum(scale_e, np.abs(en)))
+        rel('vmc wf', out['wf_abs_log'][0], wf, np.maximum(1.0, np.abs(wf)))
         v.close()
         d = DmcEnsemble(eng, 1e-300, W, W, 0.5, rng_seed=1)
         d.set_state(pos)
         d.set_tape(np.zeros(2 * W), np.zeros(2 * W * n), [0, W], [0, W * n])
         d.run_block(2)
         st = d.get_state()
-        assert np.all(np.abs(st.energy[:W] - en) <= 2e-11 * np.maximum(
-            scale_e, np.abs(en))), (kw, 'dmc energy',
-                                    np.abs(st.energy[:W] - en) / scale_e)
-        sc = np.maximum(1.0, np.abs(fd).max(1))[:, None]
-        assert np.all(np.abs(st.confs[:W, 1] - fd) <= 2e-11 * sc), \
-            (kw, 'dmc drift', (np.abs(st.confs[:W, 1] - fd) / sc).max())
+        rel('dmc energy', st.energy[:W], en, np.maximum(scale_e, np.abs(en)))
+        rel('dmc drift', st.confs[:W, 1], fd,
+            np.maximum(1.0, np.abs(fd).max(1))[:, None])
         d.close()
         # (the two random rows may fail the far-partner check -- three
         # evaluations each here --; the four spread rows never)
         assert eng.general_path_walkers() <= 6, kw
         eng.close()
         done += 1
+    print(f'{done} models ({tried} drawn); worst deviation / tolerance scale:',
+          {k: f'{v:.2e}' for k, v in worst.items()})
