@@ -123,6 +123,27 @@ __device__ __forceinline__ long long qmc_uniform(long long v)
 #define QMC_VMC_TWO_PASS 1
 #endif
 
+// The second normal of a Box-Muller pair is kept for the next time step of the
+// slot (1) or computed again there (0: same stream, no `spare` array -- 8 N
+// bytes less to write on even and to read on odd steps, a Philox block, a
+// logarithm, a square root and a sincos per particle more on odd ones;
+// VERDICT r3 item 5 asked for the A/B: profiles/r04_ab_variants.txt, 10).
+// Measured (same box): without the cache the N = 64 step is 2.5 % slower
+// (0.4775 against 0.4658 ms; 865 against 800 vector instructions per
+// walker-step) with 2374 instead of 2885 bytes of HBM traffic per walker-step
+// (1.13x the algorithmic bytes instead of 1.37x); at N = 128, where the
+// pair loop is four times the per-particle work, the two tie (1.272 / 1.279
+// ms).  The kernel is nowhere near the HBM roofline, so one particle per lane
+// keeps the cache; two or more per lane do without it -- 1 KiB less traffic
+// per walker-step at N = 128 and no 4.3 GB array at 2^22 walkers.
+#ifndef QMC_DMC_SPARE
+#define QMC_DMC_SPARE 1
+#endif
+template <int P>
+struct DmcSpare {
+    static constexpr bool ON = QMC_DMC_SPARE && P == 1;
+};
+
 // odd-even transposition passes (resort_step) run every this many steps
 #ifndef QMC_RESORT_EVERY
 #define QMC_RESORT_EVERY 4
@@ -609,7 +630,7 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
             double g;
             if (a.g_tape) {
                 g = a.g_tape[sr * n + li];
-            } else if ((step & 1u) && sr < spare_nw) {
+            } else if (DmcSpare<P>::ON && (step & 1u) && sr < spare_nw) {
                 // odd step: the sine-branch normal stored by the even step
                 g = a.spare[sr * n + li];
             } else {
@@ -619,7 +640,8 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
                 philox_normal2(a.seed, a.slot0 + (unsigned)sr, step >> 1,
                                (unsigned)li, STREAM_DMC_DIFFUSE, g0, g1);
                 g = (step & 1u) ? g1 : g0;
-                if (!(step & 1u) && active) a.spare[sr * n + li] = g1;
+                if (DmcSpare<P>::ON && !(step & 1u) && active)
+                    a.spare[sr * n + li] = g1;
             }
             // ith_diffusion (qmc_base/jastrow/dmc.py:661-671)
             double zn = z0 + 2 * f0 * a.dt + a.sigma * g;

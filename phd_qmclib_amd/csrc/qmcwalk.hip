@@ -1451,7 +1451,11 @@ extern "C" int qmc_dmc_create(qmc_engine *e, const qmc_dmc_params *p,
               dev_alloc(&d->label[b], W * n) ||
               dev_alloc(&d->energy[b], W) || dev_alloc(&d->weight[b], W);
     }
-    rc = rc || dev_alloc(&d->eslot, W) || dev_alloc(&d->spare, W * n) ||
+    // (the cached second Box-Muller normal: one particle per lane only,
+    // qmc_kernels.h: DmcSpare)
+    const bool need_spare = QMC_DMC_SPARE && e->P == 1;
+    rc = rc || dev_alloc(&d->eslot, W) ||
+         (need_spare && dev_alloc(&d->spare, W * n)) ||
          dev_alloc(&d->ref, W) ||
          dev_alloc(&d->count, W) || dev_alloc(&d->block_tot, d->nblocks) ||
          dev_alloc(&d->block_off, d->nblocks) ||
