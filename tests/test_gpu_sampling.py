@@ -612,3 +612,36 @@ def test_dmc_n64_statistics_vs_oracle(oracle):
         assert abs(t) < crit, (name, report)
     assert 14.5 < dev[:, 0].mean() < 16.5
     eng.close()
+
+
+@pytest.mark.parametrize('n', [100, 128])
+def test_dmc_large_n_equal_seed_trajectories(oracle, n):
+    """BASELINE configs[3] is DMC at N = 128 (two particles per lane: the
+    sorted-row pair sum of csrc/qmc_sorted128.h with its cotangent / tangent
+    tables, no cached second normal).  On EQUAL seeds the device must follow the
+    oracle's ensemble through branching for many steps: population identical
+    step by step, E_t and E_ref to rounding (qmc_base/dmc.py:739-785,
+    jastrow/dmc.py:758-825); N = 100 is the padded ring of 50 lanes."""
+    from phd_qmclib_amd.engine import DmcEnsemble, ModelEngine
+    spec = box(n)
+    m = oracle.model_from_cfc(spec.cfc_spec)
+    eng = ModelEngine(spec.cfc_spec)
+    dt, target, maxw, steps = 1e-3, 96, 128, 120
+    # spread like equilibrated walkers (the sorted-row path takes them all)
+    rng = np.random.RandomState(1280 + n)
+    start = (np.arange(n) + 0.5 + 0.5 * (rng.random_sample((target, n)) - 0.5))
+    eng.general_path_walkers(reset=True)
+    for seed in (41, 42):
+        d = DmcEnsemble(eng, dt, maxw, target, 0.5, rng_seed=seed)
+        d.set_state(start)
+        ser = d.run_block(steps)
+        d.close()
+        o = oracle.DmcEnsemble(m, start, dt, maxw, target, 0.5, seed=seed,
+                               nthreads=oracle.max_threads())
+        for t in range(steps):
+            y = o.step()
+            assert int(ser.num_walkers[t]) == y.num_walkers, (seed, t)
+            assert ser.energy[t] == pytest.approx(y.energy, rel=1e-9), (seed, t)
+            assert ser.ref_energy[t] == pytest.approx(y.ref_energy, rel=1e-9)
+    assert eng.general_path_walkers() == 0
+    eng.close()
