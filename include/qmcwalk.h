@@ -322,7 +322,9 @@ int qmc_dmc_read_series(qmc_dmc *d, int64_t nsteps, double *energy,
                         double *weight, uint64_t *num_walkers,
                         double *ref_energy, double *accum_energy);
 /* Population rebalance.  A walker record is walker_record_size doubles: pos[N],
- * drift[N], lane labels[N], energy, weight and, when estimators are set, the
+ * drift[N], lane labels[N], energy, LOG of the branching weight (the device's
+ * own storage form: records are opaque between engines of one build) and,
+ * when estimators are set, the
  * walker's forward-walking rows (S(k) parts [num_modes][3], density
  * [num_bins]).  export packs walkers [first, first+count) of the current
  * population into buf_dev; import_walkers_at writes `count` records into

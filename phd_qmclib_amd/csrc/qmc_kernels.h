@@ -558,7 +558,7 @@ struct DmcCtl {
 
 struct EvolveArgs {
     const double *ppos, *pdrift, *penergy;   // parents
-    double *cpos, *cdrift, *cenergy, *cweight; // children
+    double *cpos, *cdrift, *cenergy, *cweight; // children (cweight: log-weights)
     const unsigned short *plabel;             // parents' lane -> particle index
     unsigned short *clabel;
     double *eslot;            // energy the slot held in the previous iteration
@@ -713,7 +713,13 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
         double e_old = a.fix_stale ? e_par : e_slot;
         double mean_energy = (e_next + e_old) / 2;
         a.cenergy[s] = e_next;
-        a.cweight[s] = exp(-a.dt * (mean_energy - ref_energy));
+        // The LOGARITHM of the branching weight: the exponential (qmc_base/
+        // jastrow/dmc.py:818-825) is taken where the weight is used, by the one
+        // thread per walker of the branching kernels.  Here it is one value per
+        // wavefront, and a wavefront pays the instructions of exp() -- forty
+        // of this kernel's 800 per walker-step at N = 64 -- whatever the
+        // number of lanes that need the result.
+        a.cweight[s] = -a.dt * (mean_energy - ref_energy);
         a.eslot[s] = e_par;
     }
     QMC_SECTION("end");

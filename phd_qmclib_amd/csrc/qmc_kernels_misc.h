@@ -7,7 +7,8 @@
 #include "qmc_kernels.h"
 
 struct BranchArgs {
-    const double *weight;     // parent weights [maxw]
+    const double *weight;     // LOGARITHMS of the parent weights [maxw] (the
+                              // device keeps log-weights: dmc_evolve_kernel)
     const double *energy;     // parent energies [maxw]
     int *count;               // clone counts [maxw]
     long long *block_tot;     // [nblocks]
@@ -45,7 +46,7 @@ __device__ __forceinline__ void branch_count_tile(const BranchArgs &a, int tile)
                                  STREAM_DMC_BRANCH, u, u1);
             // a runaway weight must not overflow the conversion: no parent
             // can have more children than the population cap
-            const double wc = fmin(a.weight[s] + u, (double)a.maxw);
+            const double wc = fmin(exp(a.weight[s]) + u, (double)a.maxw);
             c = (int)wc;
             a.count[s] = c;
         }

@@ -1579,9 +1579,9 @@ static int dmc_set_state_impl(qmc_dmc *d, int64_t nw, const double *pos,
     PrepArgs a{ d->pos[0], d->drift[0], d->energy[0], (long long)nw };
     int rc = dispatch_shape<LaunchPrep>(e, a);
     if (rc) return rc;
-    std::vector<double> ones((size_t)nw, 1.0), en((size_t)nw);
-    HIP_TRY(hipMemcpyAsync(d->weight[0], ones.data(), (size_t)nw * sizeof(double),
-                           hipMemcpyHostToDevice, e->stream));
+    std::vector<double> en((size_t)nw);
+    // unit weights; the device keeps LOG weights (dmc_evolve_kernel)
+    HIP_TRY(hipMemsetAsync(d->weight[0], 0, (size_t)nw * sizeof(double), e->stream));
     HIP_TRY(hipMemcpyAsync(en.data(), d->energy[0], (size_t)nw * sizeof(double),
                            hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(d->eslot, d->energy[0], (size_t)nw * sizeof(double),
@@ -1649,7 +1649,12 @@ extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
                            hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d->energy[0], energy, (size_t)nw * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d->weight[0], weight, (size_t)nw * sizeof(double),
+    // the device keeps LOG weights (dmc_evolve_kernel); a weight <= 0 has no
+    // children either way
+    std::vector<double> logw((size_t)nw);
+    for (size_t i = 0; i < (size_t)nw; ++i)
+        logw[i] = weight[i] > 0.0 ? std::log(weight[i]) : -HUGE_VAL;
+    HIP_TRY(hipMemcpyAsync(d->weight[0], logw.data(), (size_t)nw * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
     // the reference copies the whole props.energy array of the initial state
     // into its `actual` buffer (qmc_base/dmc.py:707-708), stale tail included
@@ -2198,9 +2203,11 @@ extern "C" int qmc_dmc_get_state(qmc_dmc *d, double *confs, double *energy,
     }
     if (weight) {
         for (size_t s = 0; s < W; ++s) weight[s] = s < (size_t)nw ? 1.0 : 0.0;
-        if (!d->stepped)
+        if (!d->stepped) {
             HIP_TRY(hipMemcpy(weight, d->weight[d->cur], (size_t)nw * 8,
                               hipMemcpyDeviceToHost));
+            for (size_t s = 0; s < (size_t)nw; ++s) weight[s] = std::exp(weight[s]);
+        }
     }
     if (mask)
         for (size_t s = 0; s < W; ++s) mask[s] = s < (size_t)nw ? 0 : 1;
