@@ -1386,6 +1386,8 @@ struct qmc_dmc {
     std::vector<long long> u_off, g_off;
     long long tape_step = 0;
     bool stepped = false;        // a step has run since the last set_state
+    std::vector<double> init_weight;   // weights of set_full_state as given (the
+                                       // device keeps their logarithms)
     bool sums_pending = false;   // E_t partials still to be summed (by finish)
     double global_target = 0.0;
     // estimators (f1)
@@ -1513,6 +1515,7 @@ static int dmc_reset_ctl(qmc_dmc *d, long long nw, double ref_energy)
 
 static int dmc_zero_population(qmc_dmc *d)
 {
+    d->init_weight.clear();
     qmc_engine *e = d->eng;
     const size_t n = (size_t)e->dm.n, W = (size_t)d->maxw;
     for (int b = 0; b < 2; ++b) {
@@ -1652,6 +1655,7 @@ extern "C" int qmc_dmc_set_full_state(qmc_dmc *d, int64_t nw,
     // the device keeps LOG weights (dmc_evolve_kernel); a weight <= 0 has no
     // children either way
     std::vector<double> logw((size_t)nw);
+    d->init_weight.assign(weight, weight + nw);
     for (size_t i = 0; i < (size_t)nw; ++i)
         logw[i] = weight[i] > 0.0 ? std::log(weight[i]) : -HUGE_VAL;
     HIP_TRY(hipMemcpyAsync(d->weight[0], logw.data(), (size_t)nw * sizeof(double),
@@ -2203,7 +2207,9 @@ extern "C" int qmc_dmc_get_state(qmc_dmc *d, double *confs, double *energy,
     }
     if (weight) {
         for (size_t s = 0; s < W; ++s) weight[s] = s < (size_t)nw ? 1.0 : 0.0;
-        if (!d->stepped) {
+        if (!d->stepped && d->init_weight.size() == (size_t)nw) {
+            std::copy(d->init_weight.begin(), d->init_weight.end(), weight);
+        } else if (!d->stepped) {
             HIP_TRY(hipMemcpy(weight, d->weight[d->cur], (size_t)nw * 8,
                               hipMemcpyDeviceToHost));
             for (size_t s = 0; s < (size_t)nw; ++s) weight[s] = std::exp(weight[s]);
@@ -2279,6 +2285,7 @@ extern "C" int qmc_dmc_import_walkers_at(qmc_dmc *d, int64_t first,
                     "max_num_walkers");
     qmc_engine *e = d->eng;
     HIP_TRY(hipSetDevice(e->device));
+    d->init_weight.clear();
     const WalkerRecArgs a = walker_rec_args(d, first, count);
     long long tot = count * (long long)(3 * a.n + 2 + a.m3 + a.nb);
     hipLaunchKernelGGL(unpack_walkers_kernel,
@@ -2296,6 +2303,7 @@ extern "C" int qmc_dmc_set_num_walkers(qmc_dmc *d, int64_t nw)
     if (!d) return fail("qmc_dmc_set_num_walkers: null argument");
     if (nw < 0 || nw > d->maxw)
         return fail("qmc_dmc_set_num_walkers: bad population size");
+    d->init_weight.clear();
     qmc_engine *e = d->eng;
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(dmc_set_nw_kernel, dim3(1), dim3(64), 0, e->stream,

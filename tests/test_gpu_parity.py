@@ -191,6 +191,53 @@ def test_dmc_tape_replay_one_block(engines, golden_dmc_tape):
     ens.close()
 
 
+def test_dmc_initial_weights_reach_the_branching(engines, golden_kernels):
+    """`set_full_state` with weights that are not 1 (a continued run hands over
+    the last state of the previous one, mrbp_qmc/dmc.py:246-262): the state
+    reads back as given to the bit, and the first branching takes
+    int(w + u) children of every walker (qmc_base/jastrow/dmc.py:860-878),
+    zero included, the cap of max_num_walkers respected.  The device keeps
+    the LOGARITHMS of the weights (dmc_evolve_kernel): this is the one place
+    where a caller's weights are converted."""
+    from phd_qmclib_amd.engine import DmcEnsemble
+    tag = 'box16'
+    eng = engines(tag)
+    pos = np.tile(golden_kernels[tag + '/pos'], (2, 1))[:12]
+    W, n = pos.shape
+    maxw = 40
+    d = DmcEnsemble(eng, 1e-300, maxw, W, 0.5, rng_seed=1)
+    d.set_state(pos)
+    st = d.get_state()
+    assert np.array_equal(st.weight[:W], np.ones(W))
+    w = np.array([0.0, 0.3, 0.5, 1.0, 1.0 - 2.0 ** -53, 1.7, 2.3, 3.999, 1e-320,
+                  0.95, 2.0, 1.25])
+    # (w = 1 is exact -- log 1 = 0 -- and it is the weight every state the
+    # library itself yields carries; for other weights exp(log w) may sit one
+    # ulp from w, so the draws here keep w + u off the integers)
+    u = np.array([0.9, 0.69, 0.51, 0.0, 0.25, 0.31, 0.69, 0.0009, 0.999,
+                  0.05, 0.999, 0.74])
+    d.set_full_state(st.confs[:W], st.energy[:W], w, st.ref_energy)
+    st1 = d.get_state()
+    assert np.array_equal(st1.weight[:W], w) and not st1.weight[W:].any()
+    assert np.array_equal(st1.energy[:W], st.energy[:W])
+    kids = (w + u).astype(np.int64)
+    nw1 = int(kids.sum())
+    assert 0 < nw1 <= maxw
+    d.set_tape(u, np.zeros(nw1 * n), [0], [0])
+    ser = d.run_block(1)
+    assert int(ser.num_walkers[0]) == nw1
+    st2 = d.get_state()
+    assert np.array_equal(st2.cloning_ref[:nw1], np.repeat(np.arange(W), kids))
+    # the children sit where their parents sat, with their parents' energies
+    par = st2.cloning_ref[:nw1]
+    assert np.abs(st2.confs[:nw1, 0] - st.confs[par, 0]).max() <= 1e-250
+    assert close(st2.energy[:nw1], st.energy[par])
+    assert np.array_equal(st2.weight[:nw1], np.ones(nw1))
+    # total weight of the yield: one per child (unit weights after branching)
+    assert ser.weight[0] == nw1
+    d.close()
+
+
 def test_vmc_philox_matches_oracle(engines, oracle, golden_params):
     """Same seed, same counter RNG: device chains and oracle chains follow the
     same trajectories (Philox4x32-10 keyed by (seed; chain, step, particle,
