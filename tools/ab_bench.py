@@ -22,6 +22,10 @@ ap.add_argument('--equil', type=int, default=200)
 ap.add_argument('--tag', default='')
 ap.add_argument('--fast', action='store_true', help='float pair loop')
 ap.add_argument('--no-dmc', action='store_true')
+ap.add_argument('--start', default='random', choices=['random', 'lattice', 'stationary'],
+                help='lattice: one particle per well, +-0.15 around its centre; '
+                     'stationary: copies of a seed ensemble relaxed for 30 000 '
+                     'steps (tools/_stationary.py), as bench.py')
 a = ap.parse_args()
 n = a.bosons
 spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
@@ -29,6 +33,12 @@ spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
 eng = ModelEngine(spec.cfc_spec, device=0, fast_math=a.fast)
 rng = np.random.RandomState(1)
 pos = n * rng.random_sample((a.walkers, n))
+if a.start == 'stationary':
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _stationary import replicate, seed_configurations
+    pos = replicate(seed_configurations(eng, spec, n), a.walkers)
+elif a.start == 'lattice':
+    pos = np.arange(n)[None, :] + 0.25 + 0.3 * (rng.random_sample((a.walkers, n)) - 0.5)
 v = VmcEnsemble(eng, a.walkers, 0.25 * spec.well_width, rng_seed=1)
 v.set_state(pos)
 del pos

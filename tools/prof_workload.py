@@ -19,6 +19,10 @@ ap.add_argument('--steps', type=int, default=8)
 ap.add_argument('--launches', type=int, default=2)
 ap.add_argument('--equil', type=int, default=0, help='untimed steps first (VMC)')
 ap.add_argument('--fast', action='store_true', help='float pair loop')
+ap.add_argument('--start-file', default='',
+                help='.npy of seed configurations (tools/make_stationary.py): the '
+                     'walkers start from copies of them instead of a uniform '
+                     'random row, and --equil steps take the copies apart')
 a = ap.parse_args()
 n = a.bosons
 spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
@@ -26,6 +30,10 @@ spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
 eng = ModelEngine(spec.cfc_spec, device=0, fast_math=a.fast)
 rng = np.random.RandomState(1)
 pos = n * rng.random_sample((a.walkers, n))
+if a.start_file:
+    seed = np.load(a.start_file)
+    pos = np.ascontiguousarray(
+        np.tile(seed, (-(-a.walkers // len(seed)), 1))[:a.walkers])
 if a.kind == 'vmc':
     v = VmcEnsemble(eng, a.walkers, 0.25 * spec.well_width, rng_seed=1)
     v.set_state(pos)

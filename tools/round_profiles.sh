@@ -21,8 +21,12 @@ if [ "$what" = bench ] || [ "$what" = all ]; then
   [ -n "$f" ] && cp $f $out/bench_kernel_stats.csv
 fi
 if [ "$what" = pmc ] || [ "$what" = all ]; then
-  PMC_LAST=16 $R/tools/profile.sh $tag/vmc64 vmc --walkers 262144 --steps 16 --launches 1 --equil 300 > /dev/null 2>&1
-  PMC_LAST=16 $R/tools/profile.sh $tag/dmc64 dmc --walkers 262144 --steps 16 --equil 100 > /dev/null 2>&1
-  PMC_LAST=16 $R/tools/profile.sh $tag/dmc128 dmc --bosons 128 --walkers 65536 --steps 16 --equil 100 > /dev/null 2>&1
+  # the walkers start from the stationary state, as in bench.py (made outside
+  # the profiler: 30 000 small launches are not what the counters are for)
+  python3 $R/tools/make_stationary.py --bosons 64 --out /tmp/stationary_64.npy > $out/stationary.log 2>&1
+  python3 $R/tools/make_stationary.py --bosons 128 --out /tmp/stationary_128.npy >> $out/stationary.log 2>&1
+  PMC_LAST=16 $R/tools/profile.sh $tag/vmc64 vmc --walkers 262144 --steps 16 --launches 1 --equil 300 --start-file /tmp/stationary_64.npy > /dev/null 2>&1
+  PMC_LAST=16 $R/tools/profile.sh $tag/dmc64 dmc --walkers 262144 --steps 16 --equil 100 --start-file /tmp/stationary_64.npy > /dev/null 2>&1
+  PMC_LAST=16 $R/tools/profile.sh $tag/dmc128 dmc --bosons 128 --walkers 65536 --steps 16 --equil 100 --start-file /tmp/stationary_128.npy > /dev/null 2>&1
   for k in vmc64 dmc64 dmc128; do echo "== $k"; grep -A3 "kernel durations" $out/$k/summary.txt | head -4; tail -1 $out/$k/summary.txt; done
 fi

@@ -29,6 +29,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--bosons', type=int, default=64)
 ap.add_argument('--walkers', type=int, default=1 << 16)
 ap.add_argument('--equil', type=int, default=300)
+ap.add_argument('--start-file', default='',
+                help='.npy of stationary seed configurations')
 ap.add_argument('--plan', default='')
 a = ap.parse_args()
 n = a.bosons
@@ -56,7 +58,11 @@ dmc_cuts = [('top', ID['top']), ('load+philox+wrap', ID['load+philox+wrap']),
 rng = np.random.RandomState(1)
 W = a.walkers
 v = VmcEnsemble(eng, W, 0.25 * spec.well_width, rng_seed=1)
-v.set_state(n * rng.random_sample((W, n)))
+pos = n * rng.random_sample((W, n))
+if a.start_file:                     # (tools/make_stationary.py)
+    seed = np.load(a.start_file)
+    pos = np.ascontiguousarray(np.tile(seed, (-(-W // len(seed)), 1))[:W])
+v.set_state(pos)
 done = 0
 while done < a.equil:
     v.run_block(50, sums=False)

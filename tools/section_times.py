@@ -41,6 +41,8 @@ ap.add_argument('--bosons', type=int, default=64)
 ap.add_argument('--walkers', type=int, default=1 << 18)
 ap.add_argument('--steps', type=int, default=32)
 ap.add_argument('--equil', type=int, default=300)
+ap.add_argument('--start-file', default='',
+                help='.npy of stationary seed configurations')
 a = ap.parse_args()
 n = a.bosons
 spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
@@ -48,6 +50,10 @@ spec = Spec(lattice_depth=5 * pi ** 2, lattice_ratio=1, interaction_strength=2,
 eng = ModelEngine(spec.cfc_spec, device=0)
 rng = np.random.RandomState(1)
 pos = n * rng.random_sample((a.walkers, n))
+if a.start_file:                     # (tools/make_stationary.py)
+    seed = np.load(a.start_file)
+    pos = np.ascontiguousarray(
+        np.tile(seed, (-(-a.walkers // len(seed)), 1))[:a.walkers])
 v = VmcEnsemble(eng, a.walkers, 0.25 * spec.well_width, rng_seed=1)
 v.set_state(pos)
 done = 0
