@@ -93,6 +93,16 @@
 #ifndef QMC_TAN
 #define QMC_TAN 1
 #endif
+
+// Trailing rotation steps without classification (one particle per lane).  In
+// the stationary ensemble of the benchmark box 15 of the 31 steps are
+// all-short leading steps, 6 have both classes in the wavefront and 9 are
+// all-long; round 3 had measured no gain from a separate trailing loop -- on
+// ensembles 320 steps after a random start, where 14 steps were mixed and 5
+// all-long (profiles/r04_ab_variants.txt section 13).
+#ifndef QMC_S64_TRAIL
+#define QMC_S64_TRAIL 1
+#endif
 // The log|psi| pass with the pair class from the positions (QMC_WF_ZCLASS): a
 // long lane computes the sine and multiplies it into the product of the long
 // factors, a short lane computes the short-range factor and multiplies it into
@@ -464,6 +474,8 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
     constexpr bool COT = SortedCot<WF, EN, REUSE>::ON;
     constexpr bool TAN = SortedCot<WF, EN, REUSE>::TAN;
     constexpr bool ZW = QMC_WF_ZCLASS && WF && !EN;   // (PL = long factors only)
+    // (1: in every pass; 2: in the passes that compute the energy)
+    constexpr bool TRAIL = QMC_S64_TRAIL == 1 || (QMC_S64_TRAIL == 2 && EN);
     typedef SortedCot<WF, EN, REUSE> RowsOf;
     R *lS = (R *)lds, *lC = lS + ROW, *lSU = lS + RowsOf::ROW_SU * ROW,
       *lCU = lS + 3 * ROW, *lZ = lS + RowsOf::ROW_Z * ROW;
@@ -708,6 +720,38 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                 q_fold(PS, eS);
                 q_fold(PL, eL);
             }
+            // the row ascends: a lane's partners only get farther, so once
+            // no lane had a short pair in a step none will in a later one
+            if (TRAIL && __builtin_amdgcn_ballot_w64(shb & live) == 0ull)
+                break;
+        }
+        // ---- trailing steps: every pair is long-range, no classification ----
+        if (TRAIL) {
+            QMC_SECTION("rotation");
+#define QMC_S64_LONG(cs, cc)                                                  \
+            {                                                                 \
+                const R Y = COT ? (cs) - o.s : o.s * (cc) - o.c * (cs);       \
+                if (WF && live) PL *= Y;                                      \
+                if (EN) {                                                     \
+                    const R X = COT ? q_fma(o.s, (cs), (R)1)                  \
+                                    : o.c * (cc) + o.s * (cs);                \
+                    const R q = pair_div(X, Y);                               \
+                    QMC_S64_ADD_Q(q, k)                                       \
+                    if (live) Qall = q_fma(q, q, Qall);                       \
+                }                                                             \
+                ++k;                                                          \
+            }
+#pragma clang loop unroll(disable)
+            while (k < kfull) {
+                QMC_S64_LONG(as_, ac_)
+                // (COT: the second entry is the partner's position, which
+                // the steps after this loop classify by)
+                as_ = lds_ahead(pS - (k + 1)); ac_ = lds_ahead(pC - (k + 1));
+                QMC_S64_LONG(bs_, bc_)
+                bs_ = lds_ahead(pS - (k + 1)); bc_ = lds_ahead(pC - (k + 1));
+                if (WF && sizeof(R) == 4) q_fold(PL, eL);
+            }
+#undef QMC_S64_LONG
         }
         if (k <= kfull) {
             // an odd number of full steps was left: the last one is in the
