@@ -577,28 +577,32 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
           az = lds_ahead(pZ - 1);
         R bsu = lds_ahead(pSU - 2), bcu = TAN ? (R)0 : lds_ahead(pCU - 2),
           bz = lds_ahead(pZ - 2);
-        // (k odd at the top; both steps of a trip are full steps)
+        // (k odd at the top; both steps of a trip are full steps.  The row
+        // ascends: when the FARTHER partner of a trip is short for every lane,
+        // so is the nearer one -- one wave-wide test per trip)
 #pragma clang loop unroll(disable)
         while (k < kfull) {
-            if (!QMC_S64_ALL(az > o.zt)) break;
+            if (!QMC_S64_ALL(bz > o.zt)) {
+                if (QMC_S64_ALL(az > o.zt)) {
+                    QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
+                    ++k;
+                    if (EN) {
+                        const R q = pair_div(Xa, Ya);
+                        QMC_S64_ADD_Q(q, k - 1)
+                        Qs = q_fma(q, q, Qs);
+                    }
+                }
+                break;
+            }
             QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
             asu = lds_ahead(pSU - (k + 2));
             if (!TAN) acu = lds_ahead(pCU - (k + 2));
             az = lds_ahead(pZ - (k + 2));
-            ++k;
-            if (!QMC_S64_ALL(bz > o.zt)) {
-                if (EN) {
-                    const R q = pair_div(Xa, Ya);
-                    QMC_S64_ADD_Q(q, k - 1)
-                    Qs = q_fma(q, q, Qs);
-                }
-                break;
-            }
             QMC_S64_LEAD_XY(bsu, bcu, Xb, Yb)
-            bsu = lds_ahead(pSU - (k + 2));
-            if (!TAN) bcu = lds_ahead(pCU - (k + 2));
-            bz = lds_ahead(pZ - (k + 2));
-            ++k;
+            bsu = lds_ahead(pSU - (k + 3));
+            if (!TAN) bcu = lds_ahead(pCU - (k + 3));
+            bz = lds_ahead(pZ - (k + 3));
+            k += 2;
             if (EN) {
                 // (one reciprocal for both quotients -- r = 1 / (Ya Yb), qa = Xa r
                 // Yb -- measured no faster, 1 % slower in the VMC step: the
