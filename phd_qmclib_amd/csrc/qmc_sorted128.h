@@ -322,24 +322,18 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
         const R zt = o[1].zt;
 #pragma clang loop unroll(disable)
         while (k < kfull) {
-            // (the row ascends: when the farther step of a trip is all-short,
-            // so is the nearer one -- one wave-wide test per trip)
-            if (!QMC_S128_ALL(bz > zt)) {
-                if (QMC_S128_ALL(az > zt)) {
-                    QMC_S128_LEAD(asu[0], acu[0], asu[1], acu[1])
-                    ++k;
-                }
-                break;
-            }
+            if (!QMC_S128_ALL(az > zt)) break;
             QMC_S128_LEAD(asu[0], acu[0], asu[1], acu[1])
             asu = ld_pair(pSU - 2 * (k + 2));
             if (!TAN) acu = ld_pair(pCU - 2 * (k + 2));
             az = pZ[-2 * (k + 2)];
+            ++k;
+            if (!QMC_S128_ALL(bz > zt)) break;
             QMC_S128_LEAD(bsu[0], bcu[0], bsu[1], bcu[1])
-            bsu = ld_pair(pSU - 2 * (k + 3));
-            if (!TAN) bcu = ld_pair(pCU - 2 * (k + 3));
-            bz = pZ[-2 * (k + 3)];
-            k += 2;
+            bsu = ld_pair(pSU - 2 * (k + 2));
+            if (!TAN) bcu = ld_pair(pCU - 2 * (k + 2));
+            bz = pZ[-2 * (k + 2)];
+            ++k;
             if (WF) {
                 // (eight factors per trip)
                 int e = 0;
