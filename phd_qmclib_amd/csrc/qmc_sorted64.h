@@ -100,6 +100,34 @@
 // all-long; round 3 had measured no gain from a separate trailing loop -- on
 // ensembles 320 steps after a random start, where 14 steps were mixed and 5
 // all-long (profiles/r04_ab_variants.txt section 13).
+// unrolling of the rotation loops (experiments: -DQMC_S64_UNROLL_x=2)
+#define QMC_S64_PRAGMA_(x) _Pragma(#x)
+#define QMC_S64_PRAGMA(x) QMC_S64_PRAGMA_(x)
+#ifndef QMC_S64_UNROLL_LEAD
+#define QMC_S64_UNROLL_LEAD 0
+#endif
+#ifndef QMC_S64_UNROLL_GEN
+#define QMC_S64_UNROLL_GEN 0
+#endif
+#ifndef QMC_S64_UNROLL_TRAIL
+#define QMC_S64_UNROLL_TRAIL 0
+#endif
+#if QMC_S64_UNROLL_LEAD
+#define QMC_S64_LOOP_LEAD QMC_S64_PRAGMA(clang loop unroll_count(QMC_S64_UNROLL_LEAD))
+#else
+#define QMC_S64_LOOP_LEAD QMC_S64_PRAGMA(clang loop unroll(disable))
+#endif
+#if QMC_S64_UNROLL_GEN
+#define QMC_S64_LOOP_GEN QMC_S64_PRAGMA(clang loop unroll_count(QMC_S64_UNROLL_GEN))
+#else
+#define QMC_S64_LOOP_GEN QMC_S64_PRAGMA(clang loop unroll(disable))
+#endif
+#if QMC_S64_UNROLL_TRAIL
+#define QMC_S64_LOOP_TRAIL QMC_S64_PRAGMA(clang loop unroll_count(QMC_S64_UNROLL_TRAIL))
+#else
+#define QMC_S64_LOOP_TRAIL QMC_S64_PRAGMA(clang loop unroll(disable))
+#endif
+#define QMC_S64_LOOP_ZW QMC_S64_PRAGMA(clang loop unroll(disable))
 #ifndef QMC_S64_TRAIL
 #define QMC_S64_TRAIL 1
 #endif
@@ -579,21 +607,13 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
           bz = lds_ahead(pZ - 2);
         // (k odd at the top; both steps of a trip are full steps.  The row
         // ascends: when the FARTHER partner of a trip is short for every lane,
-        // so is the nearer one -- one wave-wide test per trip)
-#pragma clang loop unroll(disable)
+        // so is the nearer one -- one wave-wide test per trip, on az no more)
+QMC_S64_LOOP_LEAD
         while (k < kfull) {
-            if (!QMC_S64_ALL(bz > o.zt)) {
-                if (QMC_S64_ALL(az > o.zt)) {
-                    QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
-                    ++k;
-                    if (EN) {
-                        const R q = pair_div(Xa, Ya);
-                        QMC_S64_ADD_Q(q, k - 1)
-                        Qs = q_fma(q, q, Qs);
-                    }
-                }
-                break;
-            }
+            // (a last all-short step whose successor is not is left to the
+            // general steps: nothing of this trip is needed after the exit, and
+            // the loop carries neither the old product nor the old address)
+            if (!QMC_S64_ALL(bz > o.zt)) break;
             QMC_S64_LEAD_XY(asu, acu, Xa, Ya)
             asu = lds_ahead(pSU - (k + 2));
             if (!TAN) acu = lds_ahead(pCU - (k + 2));
@@ -680,7 +700,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k), az_ = lds_ahead(pZ - k);
         R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1)),
           bz_ = lds_ahead(pZ - (k + 1));
-#pragma clang loop unroll(disable)
+QMC_S64_LOOP_ZW
         while (k < kfull) {
             QMC_S64_ZW(as_, ac_, az_, k, false)
             as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
@@ -705,7 +725,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k);   // step k
         // step k + 1 (<= K + 1: inside the rows)
         R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1));
-#pragma clang loop unroll(disable)
+QMC_S64_LOOP_GEN
         while (k < kfull) {
             QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
             as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
@@ -745,7 +765,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
                 }                                                             \
                 ++k;                                                          \
             }
-#pragma clang loop unroll(disable)
+QMC_S64_LOOP_TRAIL
             while (k < kfull) {
                 QMC_S64_LONG(as_, ac_)
                 // (COT: the second entry is the partner's position, which
