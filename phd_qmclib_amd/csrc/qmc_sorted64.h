@@ -671,7 +671,11 @@ QMC_S64_LOOP_LEAD
     const bool mine = live & (!(LAST) || gl < K);                             \
     const bool sh = COT ? (cc) > o.zt          /* D' < rm */                   \
                         : q_abs(Y##_s) < sin_rm;                              \
-    if (EN) ns += __popcll(__builtin_amdgcn_ballot_w64(sh & mine));           \
+    /* (the lanes with a short pair, taken where the compare is: asked for    \
+       after the exec-masked region the mask is rebuilt from a select) */     \
+    const unsigned long long sh##_m =                                         \
+        __builtin_amdgcn_ballot_w64(sh & mine);                               \
+    if (EN) ns += __popcll(sh##_m);                                           \
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \
         asm volatile("");                      /* exec-masked, not selects */  \
@@ -746,8 +750,7 @@ QMC_S64_LOOP_GEN
             }
             // the row ascends: a lane's partners only get farther, so once
             // no lane had a short pair in a step none will in a later one
-            if (TRAIL && __builtin_amdgcn_ballot_w64(shb & live) == 0ull)
-                break;
+            if (TRAIL && shb_m == 0ull) break;
         }
         // ---- trailing steps: every pair is long-range, no classification ----
         if (TRAIL) {
@@ -767,14 +770,16 @@ QMC_S64_LOOP_GEN
             }
 QMC_S64_LOOP_TRAIL
             while (k < kfull) {
-                QMC_S64_LONG(as_, ac_)
-                // (COT: the second entry is the partner's position, which
-                // the steps after this loop classify by)
-                as_ = lds_ahead(pS - (k + 1)); ac_ = lds_ahead(pC - (k + 1));
-                QMC_S64_LONG(bs_, bc_)
-                bs_ = lds_ahead(pS - (k + 1)); bc_ = lds_ahead(pC - (k + 1));
+                // (the entries of a trip are read IN the trip: requested a
+                // trip ahead they arrive in other registers than the loop
+                // carries and cost two 64-bit moves per trip -- the latency is
+                // the other wavefronts' to hide, the moves are nobody's)
+                QMC_S64_LONG(pS[-k], pC[-k])
+                QMC_S64_LONG(pS[-k], pC[-k])
                 if (WF && sizeof(R) == 4) q_fold(PL, eL);
             }
+            as_ = pS[-k]; ac_ = pC[-k];
+            bs_ = pS[-(k + 1)]; bc_ = pC[-(k + 1)];
 #undef QMC_S64_LONG
         }
         if (k <= kfull) {
