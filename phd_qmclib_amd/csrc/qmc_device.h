@@ -120,6 +120,7 @@ struct DevModel {
     double a_long, b_long; // (pi/L) beta, (pi/L)^2 beta
     double inv_beta;       // 1 / beta
     double beta, log_am;
+    double one_minus_beta; // 1 - beta (eval_sorted64: the merged logarithm)
     // one-body (Kronig-Penney)
     double z_a, z_b, k1, kp1, e0, v0, v0d, v0_minus_e0, cf;
     int uniform_barrier;   // every barrier has the same height v_barrier

@@ -128,6 +128,11 @@
 #define QMC_S64_LOOP_TRAIL QMC_S64_PRAGMA(clang loop unroll(disable))
 #endif
 #define QMC_S64_LOOP_ZW QMC_S64_PRAGMA(clang loop unroll(disable))
+// One logarithm per lane in the log|psi| pass (pairs of lanes share the two
+// products; eval_sorted64).
+#ifndef QMC_LW_PAIRS
+#define QMC_LW_PAIRS 1
+#endif
 #ifndef QMC_S64_TRAIL
 #define QMC_S64_TRAIL 1
 #endif
@@ -853,6 +858,29 @@ QMC_S64_LOOP_TRAIL
             // (PL: the long factors alone)
             lw = fma(m.beta, log_pos(PL_d),
                      log_pos((!m.is_free && m.ob_table) ? PS_d : prod1 * PS_d));
+        } else if (QMC_LW_PAIRS && sizeof(R) == 8 && !m.is_free &&
+                   m.ob_table) {
+            // ONE logarithm per lane instead of two.  What the sum over the
+            // lanes needs is beta sum log PL + (1 - beta) sum log PS, and a
+            // wavefront pays for a logarithm per instruction sequence, not per
+            // lane: the lanes of a pair (2i, 2i + 1) exchange one product each,
+            // the even lane takes beta log(PL PL'), the odd one (1 - beta)
+            // log(PS PS').  (Products of 2 x 63 factors of the order of one:
+            // far inside the range of a double.)
+            const bool odd = gl & 1;
+            double own = odd ? PS_d : PL_d, give = odd ? PL_d : PS_d;
+            if (PAD && !live) { own = 1.0; give = 1.0; }
+            // quad_perm [1, 0, 3, 2]: the other lane of the pair
+            const double got = __hiloint2double(
+                __builtin_amdgcn_update_dpp(0, __double2hiint(give), 0xB1, 0xf,
+                                            0xf, false),
+                __builtin_amdgcn_update_dpp(0, __double2loint(give), 0xB1, 0xf,
+                                            0xf, false));
+            lw = (odd ? m.one_minus_beta : m.beta) * log_pos(own * got);
+            // (an idle lane next to the last lane in use carries that lane's
+            // short-range part; idle pairs carry nothing)
+            if (PAD && gl >= ((nl + 1) & ~1)) lw = 0.0;
+            if (!PAD || live) lw -= xoff;
         } else if (!m.is_free && m.ob_table) {
             const double lSv = log_pos(PS_d);
             lw = fma(m.beta, log_pos(PL_d) - lSv, lSv);
@@ -860,11 +888,15 @@ QMC_S64_LOOP_TRAIL
             lw = log_pos(prod1 * PS_d) +
                  m.beta * log_pos(fast_div(PL_d, PS_d));
         }
+        constexpr bool LWP = QMC_LW_PAIRS && sizeof(R) == 8 && !ZW;
+        const bool merged = LWP && !m.is_free && m.ob_table;
         if (sizeof(R) == 4)
             lw += LN2 * ((double)eS +
                          m.beta * (double)(ZW ? eL : eL - eS));
-        lw -= xoff;
-        if (PAD && !live) lw = 0.0;
+        if (!merged) {
+            lw -= xoff;
+            if (PAD && !live) lw = 0.0;
+        }
     }
     if (WF && EN) {
         wave_sum2_mfma(e_lane, lw, E, logwf);

@@ -374,6 +374,7 @@ static void build_dev_model(const qmc_model_params &p, DevModel &d)
     d.m_a_over_k2 = d.k2 != 0.0 ? -d.a_long / d.k2 : 0.0;
     d.beta = p.param_beta;
     d.inv_beta = p.param_beta != 0.0 ? 1.0 / p.param_beta : 0.0;
+    d.one_minus_beta = 1.0 - p.param_beta;
     d.log_am = log(fabs(p.param_am));
     d.z_a = 1.0 / (1.0 + p.lattice_ratio);
     d.z_b = p.lattice_ratio / (1.0 + p.lattice_ratio);
