@@ -313,8 +313,8 @@ class VmcEnsemble:
                   confs: bool = False):
         """Advance every chain by `nyield` generator yields.
         -> dict with sum_energy, sum_energy2, num_accepted ([W]) and, if
-        `series`, wf_abs_log / energy / move_stat ([nyield, W]); if `confs`,
-        pos ([nyield, W, N])."""
+        `series`, wf_abs_log / energy / move_stat ([nyield, W]) -- move_stat
+        alone with series='stat' --; if `confs`, pos ([nyield, W, N])."""
         W = self.num_chains
         out = {}
         se = se2 = na = swf = sen = sst = spos = None
@@ -323,7 +323,10 @@ class VmcEnsemble:
         if sums:
             se, se2 = np.zeros(W), np.zeros(W)
             na = np.zeros(W, dtype=np.int64)
-        if series:
+        if series == 'stat':
+            # (the move status alone: one byte per chain and yield)
+            sst = np.zeros((nyield, W), dtype=np.uint8)
+        elif series:
             swf, sen = np.zeros((nyield, W)), np.zeros((nyield, W))
             sst = np.zeros((nyield, W), dtype=np.uint8)
         check(self._lib.qmc_vmc_run_block(self._h, int(nyield), ptr(se),
@@ -334,7 +337,9 @@ class VmcEnsemble:
             out.update(pos=spos)
         if sums:
             out.update(sum_energy=se, sum_energy2=se2, num_accepted=na)
-        if series:
+        if series == 'stat':
+            out.update(move_stat=sst.astype(bool))
+        elif series:
             out.update(wf_abs_log=swf, energy=sen, move_stat=sst.astype(bool))
         return out
 
