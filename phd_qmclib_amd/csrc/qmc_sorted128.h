@@ -254,6 +254,9 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                     : (oa).c * (cc) + (oa).s * (cs); /* cos(pi D' / L) */      \
     const bool sh = COT ? (cc) > (oa).zt             /* D' < rm */             \
                         : q_abs(Y##_s) < sin_rm;                              \
+    /* (the mask of the lanes with a short pair, taken where the compare is:  \
+       asked for after the exec-masked region it is rebuilt from a select) */ \
+    const unsigned long long sh##_m = __builtin_amdgcn_ballot_w64(sh);        \
     R Y = Y##_s;                                                              \
     if (sh) {                                                                 \
         asm volatile("");                                                     \
@@ -280,7 +283,7 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
             const R q = pair_div(X, Y);
             Fr[1] += q; Fr[0] -= q;
             Qall = q_fma(q, q, Qall);
-            ns += __popcll(__builtin_amdgcn_ballot_w64(sh & live));
+            ns += __popcll(sh_m & live_mask);
             if (sh) { asm volatile(""); Qs = q_fma(q, q, Qs); }
         }
     }
@@ -387,10 +390,10 @@ __device__ __forceinline__ void eval_sorted128(const DevModel &m,
                 T[0] = (R)QMC_S128_ROR(T[0]);                                 \
                 T[1] = (R)QMC_S128_ROR(T[1]);                                 \
             }                                                                 \
-            ns += __popcll(__builtin_amdgcn_ballot_w64(h00 & mine)) +         \
-                  __popcll(__builtin_amdgcn_ballot_w64(h10 & mine)) +         \
-                  __popcll(__builtin_amdgcn_ballot_w64(h01 & mine)) +         \
-                  __popcll(__builtin_amdgcn_ballot_w64(h11 & mine));          \
+            const unsigned long long mine_m =                                 \
+                (LAST) ? __builtin_amdgcn_ballot_w64(mine) : live_mask;       \
+            ns += __popcll(h00_m & mine_m) + __popcll(h10_m & mine_m) +       \
+                  __popcll(h01_m & mine_m) + __popcll(h11_m & mine_m);        \
             if (mine) {                                                       \
                 Qall = q_fma(q00, q00, Qall); Qall = q_fma(q10, q10, Qall);   \
                 Qall = q_fma(q01, q01, Qall); Qall = q_fma(q11, q11, Qall);   \
