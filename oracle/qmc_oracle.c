@@ -177,6 +177,35 @@ double orc_philox_normal(uint64_t seed, uint32_t slot, uint32_t step,
     return g[step & 1u];
 }
 
+/* The DMC diffusion stream: one Philox2x32-10 block per (walker slot, pair of
+ * time steps, particle) -- the counter packing of the VMC move blocks under
+ * another key -- and both Box-Muller normals of it: the cosine branch at time
+ * step 2m, the sine branch at 2m + 1.  32-bit uniforms (w + 1/2) 2^-32. */
+void orc_dmc_normal2(uint64_t seed, uint32_t slot, uint32_t step2,
+                     uint32_t index, double *g)
+{
+    uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    key += 0x27D4EB2Fu;
+    key += (step2 >> 26) * 0x632BE5ABu + (slot >> 28) * 0xC2B2AE35u;
+    uint32_t c[2];
+    c[0] = ((step2 & 0x3FFFFFFu) << 6) | ((slot >> 22) & 0x3Fu);
+    c[1] = ((slot & 0x3FFFFFu) << 10) | (index & 0x3FFu);
+    philox2x32_10(c, key);
+    double u0 = ((double)c[0] + 0.5) * (1.0 / 4294967296.0);
+    double u1 = ((double)c[1] + 0.5) * (1.0 / 4294967296.0);
+    double r = sqrt(-2.0 * log(u0));
+    g[0] = r * cos(6.283185307179586476925 * u1);
+    g[1] = r * sin(6.283185307179586476925 * u1);
+}
+
+double orc_dmc_normal(uint64_t seed, uint32_t slot, uint32_t step,
+                      uint32_t index)
+{
+    double g[2];
+    orc_dmc_normal2(seed, slot, step >> 1, index, g);
+    return g[step & 1u];
+}
+
 /* ------------------------------------------------------------------ */
 /* Model functions                                                     */
 /* ------------------------------------------------------------------ */
@@ -556,10 +585,9 @@ void orc_dmc_step(const orc_model *m, const orc_dmc_cfg *cfg,
         /* evolve_system (:758-825); ith_diffusion (:645-671) */
         for (int64_t i = 0; i < nop; ++i) {
             double g = g_tape ? g_tape[s * nop + i]
-                              : orc_philox_normal(cfg->seed,
-                                                  cfg->slot0 + (uint32_t)s,
-                                                  st->step, (uint32_t)i,
-                                                  ORC_STREAM_DMC_DIFFUSE);
+                              : orc_dmc_normal(cfg->seed,
+                                               cfg->slot0 + (uint32_t)s,
+                                               st->step, (uint32_t)i);
             double rnd = 0 + sigma * g;
             double z_next = pc[i] + 2 * pc[nop + i] * dt + rnd;
             double z = recast(z_next, 0., 1. * L);

@@ -62,6 +62,10 @@ void orc_vmc_move_block(uint64_t seed, uint32_t slot, uint32_t step,
 double orc_vmc_move_unit(uint32_t w0);
 double orc_vmc_accept_uniform(uint32_t w1_p0, uint32_t w1_p1);
 /* DMC diffusion normal: steps 2m / 2m+1 share one block (cos / sin branch) */
+void orc_dmc_normal2(uint64_t seed, uint32_t slot, uint32_t step2,
+                     uint32_t index, double *g);
+double orc_dmc_normal(uint64_t seed, uint32_t slot, uint32_t step,
+                      uint32_t index);
 double orc_philox_normal(uint64_t seed, uint32_t slot, uint32_t step,
                          uint32_t index, uint32_t stream);
 

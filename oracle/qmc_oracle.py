@@ -148,6 +148,9 @@ def lib():
         L.orc_philox_uniform2.restype = None
         L.orc_philox_uniform2.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.c_uint32, C.c_uint32, _dp]
+        L.orc_dmc_normal.restype = C.c_double
+        L.orc_dmc_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
+                                     C.c_uint32]
         L.orc_philox_normal.restype = C.c_double
         L.orc_philox_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_uint32]
@@ -259,6 +262,12 @@ def vmc_move_unit(w0):
 
 def vmc_accept_uniform(w1_p0, w1_p1):
     return float(lib().orc_vmc_accept_uniform(w1_p0, w1_p1))
+
+
+def dmc_normal(seed, slot, step, index):
+    """The standard normal that moves particle `index` of walker slot `slot`
+    at DMC time step `step` (Philox2x32-10 block of the step pair)."""
+    return float(lib().orc_dmc_normal(seed, slot, step, index))
 
 
 def philox_normal(seed, slot, step, index, stream):

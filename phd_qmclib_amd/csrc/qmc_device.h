@@ -298,6 +298,37 @@ __device__ __forceinline__ void philox_normal2(uint64_t seed, uint32_t slot,
     g1 = r * s;
 }
 
+// The DMC diffusion stream (same definition in oracle/qmc_oracle.c:
+// orc_dmc_normal): one Philox2x32-10 block per (walker slot, pair of time
+// steps, particle) -- the counter packing of the VMC move blocks under another
+// key -- and both Box-Muller normals of it: the cosine branch moves the
+// particle at time step 2m, the sine branch at 2m + 1.  The two uniforms carry
+// 32 bits each, (w + 1/2) 2^-32 in (0, 1): a normal is cut off at 6.76 sigma
+// (2^-33 of the radial weight) and its angle is resolved to 1.5e-9.  Round 4
+// drew 2 x 53 bits from a Philox4x32 block here: 20 wide multiplies and 40
+// xors per block instead of 10 and 20, four conversions instead of two -- and
+// two particles per lane (no spare row) draw a block per particle and step.
+__device__ __forceinline__ void dmc_normal2(uint64_t seed, uint32_t slot,
+                                            uint32_t step2, uint32_t index,
+                                            double &g0, double &g1)
+{
+    uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    key += 0x27D4EB2Fu;      // (apart from the VMC move blocks of the seed)
+    key += (step2 >> 26) * 0x632BE5ABu + (slot >> 28) * 0xC2B2AE35u;
+    uint32_t w0 = ((step2 & 0x3FFFFFFu) << 6) | ((slot >> 22) & 0x3Fu);
+    uint32_t w1 = ((slot & 0x3FFFFFu) << 10) | (index & 0x3FFu);
+    philox2x32_10(w0, w1, key);
+    // (one conversion and one fused multiply-add each, exact)
+    const double u0 = fma((double)w0, 0x1p-32, 0x1p-33);
+    const double u1 = fma((double)w1, 0x1p-32, 0x1p-33);
+    // u0 <= 1 - 2^-33: the logarithm is < 0
+    const double r = fast_sqrt(-2.0 * log_pos(u0));
+    double s, c;
+    sincos_halfpi(4.0 * u1, s, c);          // angle 2 pi u1
+    g0 = r * c;
+    g1 = r * s;
+}
+
 // ------------------------------------------------------------ helpers ----
 // Periodic wrap into [0, L) with the reference's floor-mod result
 // (qmc_base/utils.py:55-66) for excursions of less than one box length.

@@ -637,8 +637,8 @@ dmc_evolve_kernel(const DevModel *__restrict__ mp, EvolveArgs a)
                 // time steps 2m, 2m+1 share one Philox block: cosine branch
                 // now, sine branch kept for the next step of this slot
                 double g0, g1;
-                philox_normal2(a.seed, a.slot0 + (unsigned)sr, step >> 1,
-                               (unsigned)li, STREAM_DMC_DIFFUSE, g0, g1);
+                dmc_normal2(a.seed, a.slot0 + (unsigned)sr, step >> 1,
+                            (unsigned)li, g0, g1);
                 g = (step & 1u) ? g1 : g0;
                 if (DmcSpare<P>::ON && !(step & 1u) && active)
                     a.spare[sr * n + li] = g1;

@@ -158,6 +158,44 @@ def test_philox2x32_known_answer(oracle):
         ((0x12345678 >> 5) << 26) | (0x9abcdef0 >> 6)) / 2.0 ** 53
 
 
+def test_dmc_normal_stream_definition(oracle):
+    """The DMC diffusion stream (oracle/qmc_oracle.c: orc_dmc_normal2): one
+    Philox2x32-10 block per (walker slot, pair of time steps, particle) under
+    the seed's key + 0x27D4EB2F, 32-bit uniforms (w + 1/2) 2^-32, Box-Muller:
+    cosine branch at step 2m, sine branch at 2m + 1.  Restated here from the
+    block function pinned by the Random123 vectors above; and the moments of
+    40 000 draws."""
+    import math
+    seed = 0x0123456789abcdef
+    key = ((seed & 0xffffffff) ^ ((seed >> 32) * 0x85EBCA6B)) & 0xffffffff
+    key = (key + 0x27D4EB2F) & 0xffffffff
+    for slot, step, idx in ((0x2345678, 0x1abcde, 0x2a5), (0, 0, 0), (5, 7, 63)):
+        c0 = (((step >> 1) & 0x3ffffff) << 6) | ((slot >> 22) & 0x3f)
+        c1 = ((slot & 0x3fffff) << 10) | idx
+        w0, w1 = oracle.philox2x32(c0, c1, key)
+        u0, u1 = (w0 + 0.5) / 2.0 ** 32, (w1 + 0.5) / 2.0 ** 32
+        r = math.sqrt(-2.0 * math.log(u0))
+        g = (r * math.cos(2 * math.pi * u1), r * math.sin(2 * math.pi * u1))
+        got = oracle.dmc_normal(seed, slot, step, idx)
+        assert abs(got - g[step & 1]) <= 1e-15 * max(1.0, abs(got))
+        # the other step of the pair takes the other branch of the same block
+        got2 = oracle.dmc_normal(seed, slot, step ^ 1, idx)
+        assert abs(got2 - g[(step ^ 1) & 1]) <= 1e-15 * max(1.0, abs(got2))
+    # another walker, another particle, another step pair: other blocks
+    base = oracle.dmc_normal(7, 3, 10, 5)
+    assert oracle.dmc_normal(7, 4, 10, 5) != base
+    assert oracle.dmc_normal(7, 3, 12, 5) != base
+    assert oracle.dmc_normal(7, 3, 10, 6) != base
+    assert oracle.dmc_normal(7, 3 + (1 << 28), 10, 5) != base
+    g = np.array([oracle.dmc_normal(11, s, t, i) for s in range(50)
+                  for t in range(20) for i in range(40)])
+    n = g.size
+    assert abs(g.mean()) < 4.0 / math.sqrt(n)
+    assert abs(g.var() - 1.0) < 4.0 * math.sqrt(2.0 / n)
+    assert abs((g ** 4).mean() - 3.0) < 4.0 * math.sqrt(96.0 / n)
+    assert np.abs(g).max() < 6.77
+
+
 def test_vmc_ndf_tape_replay(oracle, golden_params):
     """Gaussian-proposal VMC (qmc_base/vmc_ndf.py:43-59, mrbp_qmc/vmc_ndf.py):
     the oracle's chain on the reference's recorded normal()/rand() streams --
