@@ -43,9 +43,9 @@ typedef struct {
 } orc_model;
 
 /* Counter RNG shared (as an algorithm) with the device engine: Philox4x32-10,
- * key = seed, counter = (slot, step, index, stream) -- DMC branching and
- * diffusion, the Gaussian VMC proposal -- and Philox2x32-10 for the uniform
- * VMC proposal (below). */
+ * key = seed, counter = (slot, step, index, stream) -- DMC branching, the
+ * Gaussian VMC proposal -- and Philox2x32-10 for the uniform VMC proposal and
+ * the DMC diffusion normals (below). */
 enum { ORC_STREAM_VMC_MOVE = 0, ORC_STREAM_VMC_ACCEPT = 1,
        ORC_STREAM_DMC_BRANCH = 2, ORC_STREAM_DMC_DIFFUSE = 3 };
 void orc_philox_uniform2(uint64_t seed, uint32_t slot, uint32_t step,
