@@ -876,7 +876,15 @@ QMC_S64_LOOP_TRAIL
                                             0xf, false),
                 __builtin_amdgcn_update_dpp(0, __double2loint(give), 0xB1, 0xf,
                                             0xf, false));
-            lw = (odd ? m.one_minus_beta : m.beta) * log_pos(own * got);
+            // (the two coefficients as scalars: left alone, the compiler selects
+            // an ADDRESS per lane and loads the coefficient from the model in
+            // global memory)
+            int bh = __double2hiint(m.beta), bl = __double2loint(m.beta);
+            int oh = __double2hiint(m.one_minus_beta),
+                ol = __double2loint(m.one_minus_beta);
+            asm volatile("" : "+s"(bh), "+s"(bl), "+s"(oh), "+s"(ol));
+            lw = __hiloint2double(odd ? oh : bh, odd ? ol : bl) *
+                 log_pos(own * got);
             // (an idle lane next to the last lane in use carries that lane's
             // short-range part; idle pairs carry nothing)
             if (PAD && gl >= ((nl + 1) & ~1)) lw = 0.0;
