@@ -19,12 +19,21 @@
 // walker (no pair is short through the periodic image on the far side):
 //   * a pair is short iff D' < rm, always in the single (unwrapped, ordered)
 //     case: no generic branch, no sign tests;
-//   * the leading steps need ONE compare per step (partner position against
-//     z - rm) instead of three plus a scalar reduction;
+//   * the leading steps (every lane's partner short) need ONE compare per
+//     trip of two steps -- the farther partner against z - rm decides for
+//     both -- instead of three per step plus a scalar reduction;
+//   * once no lane had a short pair in a step none will later: the trailing
+//     steps run without compare, ballot, count and exec-masked region;
 //   * |a_m| is folded into the own short-range table, so log|psi| needs no
 //     count of short pairs.
-// The loops request the partner's tables one step ahead: a step is 4-15 vector
-// instructions, too few to hide an LDS round trip behind.
+// Three loops, two steps per trip: leading (all short), general (classified
+// lane by lane), trailing (all long).  In the stationary ensemble of the
+// benchmark box they run 15 / 6 / 9 of the 31 full steps.  The general loop
+// requests the partner's tables a trip ahead; the leading and the trailing
+// loops read them in the trip (round 4: requested ahead they cost register
+// moves at every back edge, and the round trip is the other wavefronts' to
+// hide -- the kernel is bound by vector issue).  A step is 3.5-12 vector
+// instructions per lane.
 // Walkers that fail the once-per-walker checks (practically never: it takes 32
 // particles inside L/4) take eval_walker, which is exact for any order.
 #pragma once
@@ -100,34 +109,6 @@
 // all-long; round 3 had measured no gain from a separate trailing loop -- on
 // ensembles 320 steps after a random start, where 14 steps were mixed and 5
 // all-long (profiles/r04_ab_variants.txt section 13).
-// unrolling of the rotation loops (experiments: -DQMC_S64_UNROLL_x=2)
-#define QMC_S64_PRAGMA_(x) _Pragma(#x)
-#define QMC_S64_PRAGMA(x) QMC_S64_PRAGMA_(x)
-#ifndef QMC_S64_UNROLL_LEAD
-#define QMC_S64_UNROLL_LEAD 0
-#endif
-#ifndef QMC_S64_UNROLL_GEN
-#define QMC_S64_UNROLL_GEN 0
-#endif
-#ifndef QMC_S64_UNROLL_TRAIL
-#define QMC_S64_UNROLL_TRAIL 0
-#endif
-#if QMC_S64_UNROLL_LEAD
-#define QMC_S64_LOOP_LEAD QMC_S64_PRAGMA(clang loop unroll_count(QMC_S64_UNROLL_LEAD))
-#else
-#define QMC_S64_LOOP_LEAD QMC_S64_PRAGMA(clang loop unroll(disable))
-#endif
-#if QMC_S64_UNROLL_GEN
-#define QMC_S64_LOOP_GEN QMC_S64_PRAGMA(clang loop unroll_count(QMC_S64_UNROLL_GEN))
-#else
-#define QMC_S64_LOOP_GEN QMC_S64_PRAGMA(clang loop unroll(disable))
-#endif
-#if QMC_S64_UNROLL_TRAIL
-#define QMC_S64_LOOP_TRAIL QMC_S64_PRAGMA(clang loop unroll_count(QMC_S64_UNROLL_TRAIL))
-#else
-#define QMC_S64_LOOP_TRAIL QMC_S64_PRAGMA(clang loop unroll(disable))
-#endif
-#define QMC_S64_LOOP_ZW QMC_S64_PRAGMA(clang loop unroll(disable))
 // One logarithm per lane in the log|psi| pass (pairs of lanes share the two
 // products; eval_sorted64).
 #ifndef QMC_LW_PAIRS
@@ -613,7 +594,7 @@ __device__ __forceinline__ void eval_sorted64(const DevModel &m, double z, int g
         // (k odd at the top; both steps of a trip are full steps.  The row
         // ascends: when the FARTHER partner of a trip is short for every lane,
         // so is the nearer one -- one wave-wide test per trip, on az no more)
-QMC_S64_LOOP_LEAD
+#pragma clang loop unroll(disable)
         while (k < kfull) {
             // (a last all-short step whose successor is not is left to the
             // general steps: nothing of this trip is needed after the exit, and
@@ -709,7 +690,7 @@ QMC_S64_LOOP_LEAD
         R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k), az_ = lds_ahead(pZ - k);
         R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1)),
           bz_ = lds_ahead(pZ - (k + 1));
-QMC_S64_LOOP_ZW
+#pragma clang loop unroll(disable)
         while (k < kfull) {
             QMC_S64_ZW(as_, ac_, az_, k, false)
             as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
@@ -734,7 +715,7 @@ QMC_S64_LOOP_ZW
         R as_ = lds_ahead(pS - k), ac_ = lds_ahead(pC - k);   // step k
         // step k + 1 (<= K + 1: inside the rows)
         R bs_ = lds_ahead(pS - (k + 1)), bc_ = lds_ahead(pC - (k + 1));
-QMC_S64_LOOP_GEN
+#pragma clang loop unroll(disable)
         while (k < kfull) {
             QMC_S64_XY(as_, ac_, k, false, Xa, Ya, sha, minea)
             as_ = lds_ahead(pS - (k + 2)); ac_ = lds_ahead(pC - (k + 2));
@@ -773,7 +754,7 @@ QMC_S64_LOOP_GEN
                 }                                                             \
                 ++k;                                                          \
             }
-QMC_S64_LOOP_TRAIL
+#pragma clang loop unroll(disable)
             while (k < kfull) {
                 // (the entries of a trip are read IN the trip: requested a
                 // trip ahead they arrive in other registers than the loop
