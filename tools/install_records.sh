@@ -14,6 +14,6 @@ python3 tools/make_traffic.py N64,profiles/${P}_vmc64_pmc_summary.txt,vmc_step_k
 (grep '^#' profiles/${P}_dynamic_sections.txt; echo; cat gpurun_out/$T/sec64.txt gpurun_out/$T/sec128.txt; echo
  grep -v amdgpu gpurun_out/$T/times64.txt; grep -v amdgpu gpurun_out/$T/times128.txt) > /tmp/ds.$$ && mv /tmp/ds.$$ profiles/${P}_dynamic_sections.txt
 grep -v amdgpu gpurun_out/$T/soak.txt > profiles/${P}_soak.txt
-grep -v amdgpu gpurun_out/$T/shape_bench.txt > profiles/${P}_shape_bench.txt
+grep -v amdgpu gpurun_out/$T/shape_bench.txt > profiles/${P}_shape_bench.txt     # (stationary ensembles)
 [ -f gpurun_out/fastmath_report.json ] && cp gpurun_out/fastmath_report.json profiles/${P}_fastmath_report.json
 grep 'valu\|salu\|sha' profiles/traffic.json
