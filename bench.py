@@ -51,7 +51,8 @@ configurations and `--equil` (320) steps with the chains' own random streams
 take the copies apart (`HipBackend.equilibrated_vmc`; the CPU baseline starts
 from the same seed configurations).  The result windows (energy per particle,
 acceptance: the stationary values) are asserted in here, and the line carries
-both.  Inputs are resident in HBM when a timed region starts.  `roofline` is the HBM view the metric contract
+both; with `--unrelaxed`, `extra.vmc_unrelaxed_start` is the same kernel on the
+old ensemble in the same run.  Inputs are resident in HBM when a timed region starts.  `roofline` is the HBM view the metric contract
 asks for: algorithmic bytes of SURVEY.md 8(d) over the dominant kernel's own
 duration, measured with HIP events on the stream it is launched on; the path
 is fp64-VALU bound, so `extra.valu` gives the pair-evaluation rate as well.
@@ -127,6 +128,12 @@ def parse_args(argv=None):
                     help='--gpus > 1: skip the same-run 1-GPU reference points '
                          '(rank 0 alone: the whole DMC population, one VMC '
                          'share) behind extra.strong_scaling / weak_scaling')
+    ap.add_argument('--unrelaxed', action='store_true',
+                    help='also time the headline kernel on the UNRELAXED ensemble '
+                         'rounds 1-3 timed (--equil steps after a uniform random '
+                         'start) as an extra line (never the headline; off by '
+                         'default: under a profiler its launches would share '
+                         'the timed instantiation\'s row of the summary)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-checks', action='store_true',
                     help='do not assert the energy / acceptance windows '
@@ -261,7 +268,7 @@ class HipBackend:
     seed_confs = {}
 
     def equilibrated_vmc(self, n, chains, chain0, equil, seed_rank,
-                         fast_math=False):
+                         fast_math=False, unrelaxed=False):
         """A VMC ensemble of `chains` chains of the N = n box IN EQUILIBRIUM.
 
         The chain relaxes slowly: from a uniform random start E/N is 15.66
@@ -283,6 +290,22 @@ class HipBackend:
         eng = self.engine(n, fast_math)
         rng = np.random.RandomState(1000 + seed_rank)
         spread = 0.25 * spec.well_width
+        if unrelaxed:
+            # what rounds 1-3 timed: `equil` steps after a uniform random start
+            v = VmcEnsemble(eng, chains, spread, rng_seed=1, chain0=chain0)
+            pos = np.empty((chains, n))
+            for lo in range(0, chains, 1 << 16):
+                hi = min(chains, lo + (1 << 16))
+                pos[lo:hi] = spec.supercell_size * rng.random_sample(
+                    (hi - lo, n))
+            v.set_state(pos)
+            del pos
+            done = 0
+            while done < equil:
+                b = min(64, equil - done)
+                v.run_block(b, sums=False)
+                done += b
+            return v
         seeds = min(chains, max(2048, chains // 64))
         # the wells of the lattice are [i, i + well_width), i = 0 ... N - 1
         pos = (np.arange(n)[None, :] + 0.5 * spec.well_width +
@@ -401,12 +424,17 @@ def load_traffic(n, kernel, path=None, loaded=None):
 
 
 # ---------------------------------------------------------------- VMC leg ---
-def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False):
+def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False,
+              unrelaxed=False):
     """Timed VMC run of this rank's W chains -> dict of raw measurements."""
     import torch
     import torch.distributed as dist
     eng = be.engine(n, fast_math)
-    vmc = be.equilibrated_vmc(n, W, rank * W, args.equil, rank, fast_math)
+    if unrelaxed:
+        vmc = be.equilibrated_vmc(n, W, rank * W, args.equil, rank, fast_math,
+                                  unrelaxed=True)
+    else:
+        vmc = be.equilibrated_vmc(n, W, rank * W, args.equil, rank, fast_math)
 
     def barrier():
         if use_pg:
@@ -969,6 +997,24 @@ def run_rank(args):
                         '(mrbp_qmc/dmc.py:159-160); NOT the headline',
             }
             mf['vmc'].close()
+        if args.unrelaxed:
+            # the same kernel on the ensemble rounds 1-3 timed, in this run on
+            # this box: the line says what the state of the ensemble is worth
+            mu = bench_vmc(be, args, rank, world, use_pg, n, W, unrelaxed=True)
+            lu = vmc_line(args, mu, n, W, world)
+            out['extra']['vmc_unrelaxed_start'] = {
+                'value': lu['value'], 'ms_per_step': lu['ms_per_step'],
+                'energy_per_particle': mu['energy_per_particle'],
+                'accept_rate': mu['accept_rate'],
+                'general_path_walkers_timed': mu['general_path_walkers'],
+                'note': f'the headline workload {args.equil} steps after a '
+                        f'uniform random start -- the ensemble bench.py timed '
+                        f'in rounds 1-3 -- instead of the stationary state: '
+                        f'more accepted moves, each with its energy pass, and '
+                        f'more rotation steps with both pair classes in a '
+                        f'wavefront; NOT the headline',
+            }
+            mu['vmc'].close()
         if not args.no_c4:
             s = bench_dmc_sharded(be, args, rank, world, use_pg)
             out['extra']['c4_dmc_sharded'] = dict(

@@ -12,7 +12,7 @@ out=$R/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 if [ "$what" = bench ] || [ "$what" = all ]; then
-  python3 $R/bench.py --steps 20 --warmup 5 --fp32 > $out/bench.json 2> $out/bench.err
+  python3 $R/bench.py --steps 20 --warmup 5 --fp32 --unrelaxed > $out/bench.json 2> $out/bench.err
   echo "bench rc=$?"
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_prof -- \
       python3 $R/bench.py --steps 20 --warmup 5 --no-cpu > $out/bench_under_rocprof.json 2> $out/bench_prof.err)
