@@ -958,6 +958,18 @@ def run_rank(args):
         dist.init_process_group(be.dist_backend, **kw)
         world = dist.get_world_size()      # what the process group reports
         rank = dist.get_rank()
+        # The first collective of a process creates the communicator (hundreds
+        # of milliseconds with RCCL).  Left to the barrier in front of the first
+        # timed region, that is hundreds of milliseconds of idle GPU right
+        # before it -- and an MI355X that has idled for more than a few
+        # milliseconds runs its next launches 15-25 % slower and needs some
+        # 30 ms to come back (`profiles/r04_ab_variants.txt` section 23).
+        # Create it here, long before anything is timed.
+        import torch
+        warm = torch.zeros(2, dtype=torch.float64, device=be.device)
+        dist.all_reduce(warm)
+        dist.barrier()
+        be.sync()
 
     n, W = args.bosons, args.chains
     out = None
