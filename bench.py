@@ -449,6 +449,11 @@ def bench_vmc(be, args, rank, world, use_pg, n, W, fast_math=False,
             done += b
         return k
 
+    # (ranks meet BEFORE the warm-up, so that they reach the barrier in front
+    # of the timed region together: a rank that waits there idles, and a GPU
+    # that idled for milliseconds starts the timed region 15-25 % slow --
+    # `profiles/r04_ab_variants.txt` section 23)
+    barrier()
     run_steps(args.warmup)
     # (device counter of walkers that leave the sorted-row pair sums: read
     # over the timed region -- which code did the timed kernel run?)
@@ -561,7 +566,9 @@ def bench_dmc_single(be, args, n, vmc, target):
     maxw = ((target * 512 // 480) + 255) // 256 * 256
     d = DmcEnsemble(eng, 6.25e-4, maxw, target, 0.5, rng_seed=1)
     d.set_state_from_vmc(vmc, target, replicate=True)
-    d.run_block(max(args.warmup, 8), read=False)
+    # (at least 64 steps, 30 ms: the population was set up just now with the
+    # GPU idle, and the chip needs that long to come back -- section 23)
+    d.run_block(max(args.warmup, 64), read=False)
     eng.sync()
     # three timed regions of --steps steps, the median reported: 20 steps are
     # 10 ms of wall clock, and one descheduling of the enqueueing thread in
